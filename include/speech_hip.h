@@ -1,0 +1,86 @@
+/* include/speech_hip.h -- batch/plan extension of the drop-in boundary (additive; C ABI).
+ *
+ * The reference has no handles: every call rebuilds its window, FFT plan, mel and lifter tables
+ * (c/kaldi_mfcc.c:105-210) and processes ONE utterance (src/kaldi_mfcc.cpp:290).  To make
+ * device-resident, ragged-batch throughput reachable the same pipeline is exposed as
+ *   plan  = the per-call tables of c/kaldi_mfcc.c:105-210, built once and kept on one device;
+ *   batch = the launch geometry for a ragged list of utterances (tile list, offsets);
+ *   run   = the per-frame loop of c/kaldi_mfcc.c:213-334 for every utterance of the batch.
+ * Plain pointers and sizes only; device pointers are what hipMalloc (or torch) returns and the
+ * stream is a hipStream_t passed as void*.  All functions return 0 on success, 1 on error
+ * (message via speech_last_error(), also printed to stderr in the reference's style).
+ * There is no CPU fallback anywhere behind this header.
+ */
+#pragma once
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SPEECH_SPECTROGRAM = 0, SPEECH_FBANK = 1, SPEECH_MFCC = 2, SPEECH_PLP = 3 };
+enum { SPEECH_F32 = 0, SPEECH_F64 = 1 };
+
+/* The union of the reference functions' option lists (c/codee_speech.h:13-25). */
+typedef struct speech_opts {
+    int kind;               /* SPEECH_* : which reference function family */
+    int dtype;              /* SPEECH_F32 = the *_s functions, SPEECH_F64 = the *_d functions */
+    double sr, frame_length, frame_shift;
+    int snip_edges;
+    double dither;          /* >FLT_EPSILON: seeded counter-based Gaussian dither (not bit-equal to the
+                               reference's wall-clock-seeded PCG, c/kaldi_mfcc.c:87-98) */
+    int dc0, raw_energy;
+    double preemph;
+    char win_type[32];
+    int amp;                /* fbank */
+    double lof, hif;        /* fbank, mfcc, plp */
+    size_t B;
+    int lg;                 /* fbank */
+    int use_energy;
+    size_t C;               /* mfcc, plp */
+    double Q;
+    double compress, cep_scale;   /* plp */
+    size_t lpc_order;       /* plp; 0 = C-1 (the drop-in rule) */
+    int mn0;
+    unsigned long long dither_seed;
+    int force_generic;      /* 1 = use the generic (any-size, any-precision) kernels even where a tuned
+                               gfx950 kernel exists; for testing */
+} speech_opts;
+
+typedef struct speech_plan speech_plan;
+typedef struct speech_batch speech_batch;
+
+/* Fill opts with the reference CLI's defaults for `kind` (srci/kaldi_mfcc.cpp:106-172), dither=0. */
+void speech_opts_default(speech_opts *opts, int kind);
+
+int speech_device_count(void);
+const char *speech_last_error(void);
+
+/* Validate opts exactly as the reference prologue does (c/kaldi_mfcc.c:54-78) and build the tables on `device`. */
+int speech_plan_create(speech_plan **plan, const speech_opts *opts, int device);
+void speech_plan_destroy(speech_plan *plan);
+/* L, stp, nfft, feature dimension D, and 1 in *tuned if a tuned gfx950 kernel serves this plan. Any pointer may be NULL. */
+int speech_plan_sizes(const speech_plan *plan, size_t *L, size_t *stp, size_t *nfft, size_t *D, int *tuned);
+/* W for an utterance of N samples; returns 1 (and *W=0) if the reference would reject N (N<1, or snip_edges && L>N). */
+int speech_plan_num_frames(const speech_plan *plan, size_t N, size_t *W);
+
+/* Geometry for nutt utterances.  x_off[u]/y_off[u] are ELEMENT offsets of utterance u inside the packed input /
+   output device arrays; pass NULL for dense packing in order (x_off[u] = sum of n_samples before u, y_off likewise
+   with W*D).  Utterances the reference would reject make this call fail. */
+int speech_batch_create(speech_batch **batch, speech_plan *plan, size_t nutt, const size_t *n_samples,
+                        const size_t *x_off, const size_t *y_off);
+void speech_batch_destroy(speech_batch *batch);
+/* totals: samples read, features written (elements), frames; and the element offsets actually used. */
+int speech_batch_totals(const speech_batch *batch, size_t *total_samples, size_t *total_out, size_t *total_frames);
+int speech_batch_offsets(const speech_batch *batch, size_t *x_off, size_t *y_off, size_t *n_frames);
+
+/* Enqueue the whole batch on `stream` (hipStream_t as void*, NULL = default stream).  X and Y are device
+   pointers of the plan's dtype.  Asynchronous: returns after the launches are queued. */
+int speech_batch_run(speech_batch *batch, const void *X_dev, void *Y_dev, void *stream);
+/* Same, but brackets the dominant (per-frame pipeline) kernel with HIP events recorded on `stream`, waits for
+   completion and returns that kernel's duration in milliseconds. */
+int speech_batch_run_timed(speech_batch *batch, const void *X_dev, void *Y_dev, void *stream, float *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif

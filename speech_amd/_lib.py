@@ -1,0 +1,85 @@
+"""ctypes binding of libspeech.so (the C ABI of include/codee_speech.h and include/speech_hip.h).
+
+The library is loaded from speech_amd/lib/ (built in-tree by speech_amd/csrc/Makefile).  There is no
+fallback of any kind: if the library is missing, loading raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspeech.so")
+
+KINDS = {"spectrogram": 0, "fbank": 1, "mfcc": 2, "plp": 3}
+F32, F64 = 0, 1
+
+LEGACY_SYMBOLS = [
+    "kaldi_fbank_s", "kaldi_fbank_d", "kaldi_fbank_default_s", "kaldi_fbank_default_d",
+    "kaldi_mfcc_s", "kaldi_mfcc_d", "kaldi_plp_s", "kaldi_plp_d",
+    "kaldi_spectrogram_s", "kaldi_spectrogram_d",
+]
+EXT_SYMBOLS = [
+    "speech_opts_default", "speech_device_count", "speech_last_error",
+    "speech_plan_create", "speech_plan_destroy", "speech_plan_sizes", "speech_plan_num_frames",
+    "speech_batch_create", "speech_batch_destroy", "speech_batch_totals", "speech_batch_offsets",
+    "speech_batch_run", "speech_batch_run_timed",
+]
+
+
+class SpeechOpts(C.Structure):
+    """Mirror of `struct speech_opts` (include/speech_hip.h)."""
+    _fields_ = [
+        ("kind", C.c_int), ("dtype", C.c_int),
+        ("sr", C.c_double), ("frame_length", C.c_double), ("frame_shift", C.c_double),
+        ("snip_edges", C.c_int), ("dither", C.c_double), ("dc0", C.c_int), ("raw_energy", C.c_int),
+        ("preemph", C.c_double), ("win_type", C.c_char * 32),
+        ("amp", C.c_int), ("lof", C.c_double), ("hif", C.c_double), ("B", C.c_size_t), ("lg", C.c_int),
+        ("use_energy", C.c_int), ("C", C.c_size_t), ("Q", C.c_double),
+        ("compress", C.c_double), ("cep_scale", C.c_double), ("lpc_order", C.c_size_t),
+        ("mn0", C.c_int), ("dither_seed", C.c_ulonglong), ("force_generic", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libspeech.so and declare every prototype.  Raises OSError if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libspeech.so not found at %s: build it with `make -C speech_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    i, z, s, vp = C.c_int, C.c_size_t, C.c_char_p, C.c_void_p
+    pz = C.POINTER(C.c_size_t)
+    for sfx, r in (("s", C.c_float), ("d", C.c_double)):
+        p = C.POINTER(r)
+        front = [p, p, z, r, r, r, i, r, i, i, r, s]
+        getattr(lib, "kaldi_spectrogram_" + sfx).argtypes = front + [i]
+        getattr(lib, "kaldi_fbank_" + sfx).argtypes = front + [i, r, r, z, i, i, i]
+        getattr(lib, "kaldi_fbank_default_" + sfx).argtypes = [p, p, z, r, i, r, i, i, r, s, i, r, r, i, i, i]
+        getattr(lib, "kaldi_mfcc_" + sfx).argtypes = front + [r, r, z, z, r, i, i]
+        getattr(lib, "kaldi_plp_" + sfx).argtypes = front + [r, r, z, r, z, r, r, i, i]
+    for name in LEGACY_SYMBOLS:
+        getattr(lib, name).restype = i
+    po = C.POINTER(SpeechOpts)
+    lib.speech_opts_default.argtypes = [po, i]; lib.speech_opts_default.restype = None
+    lib.speech_device_count.argtypes = []; lib.speech_device_count.restype = i
+    lib.speech_last_error.argtypes = []; lib.speech_last_error.restype = s
+    lib.speech_plan_create.argtypes = [C.POINTER(vp), po, i]; lib.speech_plan_create.restype = i
+    lib.speech_plan_destroy.argtypes = [vp]; lib.speech_plan_destroy.restype = None
+    lib.speech_plan_sizes.argtypes = [vp, pz, pz, pz, pz, C.POINTER(i)]; lib.speech_plan_sizes.restype = i
+    lib.speech_plan_num_frames.argtypes = [vp, z, pz]; lib.speech_plan_num_frames.restype = i
+    lib.speech_batch_create.argtypes = [C.POINTER(vp), vp, z, pz, pz, pz]; lib.speech_batch_create.restype = i
+    lib.speech_batch_destroy.argtypes = [vp]; lib.speech_batch_destroy.restype = None
+    lib.speech_batch_totals.argtypes = [vp, pz, pz, pz]; lib.speech_batch_totals.restype = i
+    lib.speech_batch_offsets.argtypes = [vp, pz, pz, pz]; lib.speech_batch_offsets.restype = i
+    lib.speech_batch_run.argtypes = [vp, vp, vp, vp]; lib.speech_batch_run.restype = i
+    lib.speech_batch_run_timed.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]; lib.speech_batch_run_timed.restype = i
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return (load().speech_last_error() or b"").decode()

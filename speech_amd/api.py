@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference interface, over the C ABI.
+
+Two levels, both thin:
+  * kaldi_spectrogram / kaldi_fbank / kaldi_mfcc / kaldi_plp -- the reference's per-utterance functions
+    (c/codee_speech.h:13-25) with the same argument names and meaning; numpy in, numpy out, host pointers
+    straight into the drop-in symbols.  A non-zero return raises SpeechError (the C side has already printed
+    the reference-style message to stderr).
+  * Plan / Batch -- the device-resident ragged-batch ABI of include/speech_hip.h, taking torch CUDA (ROCm)
+    tensors; torch is used only for device memory and streams.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+
+class SpeechError(RuntimeError):
+    pass
+
+
+def _nfft(L):
+    n = 1
+    while n < L:
+        n *= 2
+    return n
+
+
+def frame_sizes(N, sr=16000.0, frame_length=25.0, frame_shift=10.0, snip_edges=1, dtype=np.float32):
+    """(W, L, stp) as the reference derives them in the working precision (c/kaldi_mfcc.c:68-78)."""
+    t = np.float32 if np.dtype(dtype) == np.float32 else np.float64
+    L = int(t(sr) * t(frame_length) / t(1000.0))
+    stp = int(t(sr) * t(frame_shift) / t(1000.0))
+    if L < 1 or stp < 1 or N < 1 or (snip_edges and L > N):
+        return 0, L, stp
+    W = 1 + (N - L) // stp if snip_edges else (N + stp // 2) // stp
+    return W, L, stp
+
+
+def _legacy(kind, X, D_of, tail, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0):
+    lib = _lib.load()
+    X = np.ascontiguousarray(X)
+    if X.dtype not in (np.float32, np.float64):
+        X = X.astype(np.float32)
+    X = X.reshape(-1)
+    single = X.dtype == np.float32
+    ct = C.c_float if single else C.c_double
+    W, L, stp = frame_sizes(X.size, sr, frame_length, frame_shift, snip_edges, X.dtype)
+    D = D_of(max(L, 1))
+    Y = np.zeros((max(W, 1), D), dtype=X.dtype)
+    fn = getattr(lib, "kaldi_%s_%s" % (kind, "s" if single else "d"))
+    rc = fn(Y.ctypes.data_as(C.POINTER(ct)), X.ctypes.data_as(C.POINTER(ct)), X.size, sr, frame_length, frame_shift,
+            int(snip_edges), dither, int(dc0), int(raw_energy), preemph, win_type.encode(), *tail, int(mn0))
+    if rc != 0:
+        raise SpeechError(_lib.last_error() or "kaldi_%s failed" % kind)
+    return Y[:W]
+
+
+def kaldi_spectrogram(X, sr=16000.0, frame_length=25.0, frame_shift=10.0, snip_edges=1, dither=0.0, dc0=1, raw_energy=1,
+                      preemph=0.97, win_type="povey", mn0=0):
+    """reference: c/kaldi_spectrogram.c:46 (float32 input -> *_s, float64 -> *_d)"""
+    return _legacy("spectrogram", X, lambda L: _nfft(L) // 2 + 1, (), sr, frame_length, frame_shift, snip_edges, dither,
+                   dc0, raw_energy, preemph, win_type, mn0)
+
+
+def kaldi_fbank(X, sr=16000.0, frame_length=25.0, frame_shift=10.0, snip_edges=1, dither=0.0, dc0=1, raw_energy=1,
+                preemph=0.97, win_type="povey", amp=0, lof=20.0, hif=8000.0, B=23, lg=1, use_energy=0, mn0=0):
+    """reference: c/kaldi_fbank.c:59"""
+    return _legacy("fbank", X, lambda L: B + (1 if use_energy else 0), (int(amp), lof, hif, B, int(lg), int(use_energy)),
+                   sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0)
+
+
+def kaldi_mfcc(X, sr=16000.0, frame_length=25.0, frame_shift=10.0, snip_edges=1, dither=0.0, dc0=1, raw_energy=1,
+               preemph=0.97, win_type="povey", lof=20.0, hif=8000.0, B=23, C=13, Q=22.0, use_energy=0, mn0=0):
+    """reference: c/kaldi_mfcc.c:52"""
+    return _legacy("mfcc", X, lambda L: C, (lof, hif, B, C, Q, int(use_energy)),
+                   sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0)
+
+
+def kaldi_plp(X, sr=16000.0, frame_length=25.0, frame_shift=10.0, snip_edges=1, dither=0.0, dc0=1, raw_energy=1,
+              preemph=0.97, win_type="povey", lof=20.0, hif=8000.0, B=23, compress=1.0 / 3.0, C=13, Q=22.0, cep_scale=1.0,
+              use_energy=0, mn0=0):
+    """reference: c/kaldi_plp.c:53 (signature c/codee_speech.h:21)"""
+    return _legacy("plp", X, lambda L: C, (lof, hif, B, compress, C, Q, cep_scale, int(use_energy)),
+                   sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0)
+
+
+_OPT_ALIASES = {"fl": "frame_length", "fs": "frame_shift", "snip": "snip_edges", "win": "win_type", "order": "lpc_order"}
+
+
+def make_opts(kind, dtype="f32", **kw):
+    lib = _lib.load()
+    o = _lib.SpeechOpts()
+    lib.speech_opts_default(C.byref(o), _lib.KINDS[kind])
+    o.dtype = _lib.F64 if dtype in ("f64", np.float64, "double") else _lib.F32
+    # test/bench convention: Kaldi-style front end unless overridden (the CLI defaults leave dc0/raw_energy/snip_edges off)
+    o.snip_edges, o.dc0, o.raw_energy = 1, 1, 1
+    for k, v in kw.items():
+        k = _OPT_ALIASES.get(k, k)
+        if k == "win_type":
+            o.win_type = v.encode()
+        elif not hasattr(o, k):
+            raise KeyError(k)
+        else:
+            setattr(o, k, v)
+    return o
+
+
+class Plan:
+    """speech_plan: the per-call tables of c/kaldi_mfcc.c:105-210, built once on one device."""
+
+    def __init__(self, kind, device=0, dtype="f32", **kw):
+        self._lib = _lib.load()
+        self.opts = make_opts(kind, dtype, **kw)
+        self.kind = kind
+        self.device = device
+        h = C.c_void_p()
+        if self._lib.speech_plan_create(C.byref(h), C.byref(self.opts), device) != 0:
+            raise SpeechError(_lib.last_error())
+        self._h = h
+        L, stp, nfft, D, tuned = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
+        self._lib.speech_plan_sizes(h, C.byref(L), C.byref(stp), C.byref(nfft), C.byref(D), C.byref(tuned))
+        self.L, self.stp, self.nfft, self.D, self.tuned = L.value, stp.value, nfft.value, D.value, bool(tuned.value)
+        self.np_dtype = np.float64 if self.opts.dtype == _lib.F64 else np.float32
+
+    def num_frames(self, N):
+        W = C.c_size_t()
+        if self._lib.speech_plan_num_frames(self._h, N, C.byref(W)) != 0:
+            return None
+        return W.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.speech_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """speech_batch: launch geometry for a ragged list of utterances packed back to back."""
+
+    def __init__(self, plan, n_samples, x_off=None, y_off=None):
+        self._lib = _lib.load()
+        self.plan = plan
+        n = np.ascontiguousarray(n_samples, dtype=np.uint64)
+        self.nutt = int(n.size)
+        pz = C.POINTER(C.c_size_t)
+        xo = np.ascontiguousarray(x_off, dtype=np.uint64) if x_off is not None else None
+        yo = np.ascontiguousarray(y_off, dtype=np.uint64) if y_off is not None else None
+        h = C.c_void_p()
+        rc = self._lib.speech_batch_create(C.byref(h), plan._h, self.nutt, n.ctypes.data_as(pz),
+                                           xo.ctypes.data_as(pz) if xo is not None else None,
+                                           yo.ctypes.data_as(pz) if yo is not None else None)
+        if rc != 0:
+            raise SpeechError(_lib.last_error())
+        self._h = h
+        ts, to, tf = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._lib.speech_batch_totals(h, C.byref(ts), C.byref(to), C.byref(tf))
+        self.total_samples, self.total_out, self.total_frames = ts.value, to.value, tf.value
+        self.x_off = np.zeros(self.nutt, dtype=np.uint64)
+        self.y_off = np.zeros(self.nutt, dtype=np.uint64)
+        self.n_frames = np.zeros(self.nutt, dtype=np.uint64)
+        if self.nutt:
+            self._lib.speech_batch_offsets(h, self.x_off.ctypes.data_as(pz), self.y_off.ctypes.data_as(pz), self.n_frames.ctypes.data_as(pz))
+        self.n_samples = n
+
+    def run(self, X, Y, stream=None, timed=False):
+        """X, Y: torch tensors on the plan's device (1-D, plan dtype).  stream: a raw hipStream_t value
+        (e.g. torch.cuda.current_stream().cuda_stream) or None for the default stream."""
+        sp = C.c_void_p(stream) if stream else None
+        if timed:
+            ms = C.c_float()
+            rc = self._lib.speech_batch_run_timed(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()), sp, C.byref(ms))
+            if rc != 0:
+                raise SpeechError(_lib.last_error())
+            return ms.value
+        rc = self._lib.speech_batch_run(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()), sp)
+        if rc != 0:
+            raise SpeechError(_lib.last_error())
+        return None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.speech_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

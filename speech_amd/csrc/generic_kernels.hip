@@ -1,0 +1,370 @@
+// generic_kernels.hip -- any-size, any-precision per-frame pipeline (gfx950).
+//
+// One 256-thread workgroup walks a tile of consecutive frames of one utterance; the frame lives in
+// LDS from the gather to the feature epilogue.  This path serves the *_d entry points, frame lengths
+// without a tuned kernel (nfft outside 256..2048) and dither; the tuned fp32 kernels are in
+// fast_kernels.hip.  Pipeline order and arithmetic follow the reference's per-frame loop
+// (c/kaldi_mfcc.c:213-334; spectrogram epilogue c/kaldi_spectrogram.c:236-251; fbank epilogue
+// c/kaldi_fbank.c:290-350; PLP tail per SURVEY.md 8(a) row P).
+#include "speech_internal.hpp"
+#include <cfloat>
+
+namespace speech {
+
+namespace {
+
+template <typename T> struct M;
+template <> struct M<float> {
+    static __device__ __forceinline__ float log(float x) { return logf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+    static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
+    static __device__ __forceinline__ float cos(float x) { return cosf(x); }
+    static __device__ __forceinline__ float sin(float x) { return sinf(x); }
+};
+template <> struct M<double> {
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+};
+
+constexpr int NT = 256;
+
+// Sum over the workgroup; every thread returns the same value.  `red` holds NT elements.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T *red)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1)
+    {
+        if (tid < s) { red[tid] += red[tid + s]; }
+        __syncthreads();
+    }
+    return red[0];
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <typename T>
+__device__ __forceinline__ T floor_log(T v)
+{
+    const T eps = (T)FLT_EPSILON;
+    return (v < eps) ? M<T>::log(eps) : M<T>::log(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T> p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int L = p.L, nfft = p.nfft, F = p.F, B = p.B, C = p.C, P = p.P;
+    T *re = reinterpret_cast<T *>(smem_raw);
+    T *im = re + nfft;
+    T *red = im + nfft;            // NT
+    T *mel = red + NT;             // B
+    T *dup = mel + B;              // B+2
+    T *ac = dup + (B + 2);         // P+1
+    T *lpc = ac + (P + 1);         // P+1
+    T *tmp = lpc + (P + 1);        // P+1
+    T *cep = tmp + (P + 1);        // P+1
+    T *sc0 = cep + (P + 1);        // 1
+
+    const TileDesc tile = p.tiles[blockIdx.x];
+    const UttDesc utt = p.utts[tile.utt];
+    const T *x = p.X + utt.x_off;
+    const long long N = (long long)utt.n;
+    const T eps = (T)FLT_EPSILON;
+
+    for (uint32_t fi = 0; fi < tile.nframes; ++fi)
+    {
+        const long long w = (long long)tile.frame0 + fi;
+        T *y = p.Y + utt.y_off + (unsigned long long)w * (unsigned long long)p.D;
+        // frame start: c/kaldi_mfcc.c:81-82,216-240
+        const long long start = p.snip_edges ? w * p.stp : (long long)(p.stp / 2) - (long long)(L / 2) + w * p.stp;
+        __syncthreads();
+        for (int l = tid; l < nfft; l += NT)
+        {
+            T v = (T)0;
+            if (l < L)
+            {
+                long long n = start + l;
+                while (n < 0 || n >= N) { n = (n < 0) ? -n - 1 : 2 * N - 1 - n; }   // reflect: c/kaldi_mfcc.c:228
+                v = x[n];
+            }
+            re[l] = v;
+        }
+        __syncthreads();
+        if (p.do_dither)
+        {
+            // Gaussian pairs by Box-Muller as c/kaldi_mfcc.c:243-262, from a counter-based hash instead of a serial PCG state
+            for (int i = tid; 2 * i < L; i += NT)
+            {
+                const unsigned long long h = mix64(mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) + (unsigned long long)w * 0x100000001B3ull + (unsigned long long)i);
+                const unsigned long long h2 = mix64(h);
+                T u1 = (T)((double)(unsigned)(h >> 32) * 2.3283064365386963e-10);
+                const T u2 = (T)((double)(unsigned)(h2 >> 32) * 2.3283064365386963e-10);
+                if (u1 > (T)0.99999994) { u1 = (T)0.99999994; }
+                const T R = p.dither * M<T>::sqrt((T)-2 * M<T>::log((T)1 - u1));
+                const T ang = (T)6.283185307179586476925286766559 * u2;
+                re[2 * i] += R * M<T>::cos(ang);
+                if (2 * i + 1 < L) { re[2 * i + 1] += R * M<T>::sin(ang); }
+            }
+            __syncthreads();
+        }
+
+        T rawe = (T)0;
+        if (p.want_pre && p.pre_before_dc)                 // kaldi_mfcc_d only: c/kaldi_mfcc.c:576-582
+        {
+            T s = (T)0;
+            for (int l = tid; l < L; l += NT) { s += re[l] * re[l]; }
+            rawe = block_sum(s, red);
+            if (rawe < eps) { rawe = eps; }
+        }
+        if (p.dc0)                                         // c/kaldi_mfcc.c:265-271
+        {
+            T s = (T)0;
+            for (int l = tid; l < L; l += NT) { s += re[l]; }
+            const T mn = block_sum(s, red) / (T)L;
+            for (int l = tid; l < L; l += NT) { re[l] -= mn; }
+            __syncthreads();
+        }
+        if (p.want_pre && !p.pre_before_dc)                // c/kaldi_mfcc.c:274-279
+        {
+            T s = (T)0;
+            for (int l = tid; l < L; l += NT) { s += re[l] * re[l]; }
+            rawe = block_sum(s, red);
+            if (rawe < eps) { rawe = eps; }
+        }
+        // pre-emphasis (closed form of the backwards in-place loop, c/kaldi_mfcc.c:282-288) and window (:291)
+        for (int l = tid; l < nfft; l += NT)
+        {
+            T v = (T)0;
+            if (l < L)
+            {
+                v = re[l];
+                if (p.do_preemph) { v -= p.preemph * ((l > 0) ? re[l - 1] : re[0]); }
+                v *= p.win[l];
+            }
+            im[l] = v;
+        }
+        __syncthreads();
+        if (p.want_post)                                   // c/kaldi_mfcc.c:295-301
+        {
+            T s = (T)0;
+            for (int l = tid; l < L; l += NT) { s += im[l] * im[l]; }
+            rawe = block_sum(s, red);
+            if (rawe < eps) { rawe = eps; }
+        }
+        // FFT (replaces the FFTW R2HC call, c/kaldi_mfcc.c:304): radix-2 DIT on the zero-padded frame
+        for (int l = tid; l < nfft; l += NT) { re[__brev((unsigned)l) >> (32 - p.log2n)] = im[l]; }
+        __syncthreads();
+        for (int l = tid; l < nfft; l += NT) { im[l] = (T)0; }
+        __syncthreads();
+        for (int half = 1; half < nfft; half <<= 1)
+        {
+            const int tstep = nfft / (2 * half);
+            for (int i = tid; i < nfft / 2; i += NT)
+            {
+                const int k = i & (half - 1);
+                const int a = ((i - k) << 1) + k, b = a + half;
+                const T c = p.tw_re[k * tstep], s = p.tw_im[k * tstep];
+                const T tr = re[b] * c - im[b] * s;
+                const T ti = re[b] * s + im[b] * c;
+                const T ar = re[a], ai = im[a];
+                re[b] = ar - tr; im[b] = ai - ti;
+                re[a] = ar + tr; im[a] = ai + ti;
+            }
+            __syncthreads();
+        }
+        // power, c/kaldi_mfcc.c:307-310 (im[0] = im[nfft/2] = 0 for a real input up to rounding; the reference never adds them)
+        for (int k = tid; k < F; k += NT)
+        {
+            T pw = re[k] * re[k];
+            if (k > 0 && k < F - 1) { pw += im[k] * im[k]; }
+            re[k] = pw;
+        }
+        __syncthreads();
+
+        if (p.kind == SPEECH_SPECTROGRAM)
+        {
+            // c/kaldi_spectrogram.c:236-251
+            for (int k = tid; k < F; k += NT)
+            {
+                const T v = (k == 0) ? rawe : ((k == F - 1) ? re[F - 2] : re[k]);
+                y[k] = floor_log(v);
+            }
+            continue;
+        }
+
+        // sparse mel sums, c/kaldi_mfcc.c:313-320 / c/kaldi_fbank.c:312-345
+        for (int b = tid; b < B; b += NT)
+        {
+            const T *wgt = p.f2b + p.mel_off[b];
+            const int beg = p.mel_beg[b], num = p.mel_num[b];
+            T sm = (T)0;
+            for (int f = 0; f < num; ++f)
+            {
+                T pv = re[beg + f];
+                if (p.amp) { pv = M<T>::sqrt(pv); }
+                sm += pv * wgt[f];
+            }
+            mel[b] = sm;
+        }
+        __syncthreads();
+
+        if (p.kind == SPEECH_FBANK)
+        {
+            const int eo = p.use_energy ? 1 : 0;
+            for (int b = tid; b < B; b += NT)
+            {
+                const int src = (b == B - 1 && B >= 2) ? B - 2 : b;        // c/kaldi_fbank.c:350
+                const T v = mel[src];
+                T out = p.lg ? floor_log(v) : v;
+                if (B == 1 && eo) { out = M<T>::log(rawe); }
+                y[eo + b] = out;
+            }
+            if (eo && tid == 0) { y[0] = M<T>::log(rawe); }                  // c/kaldi_fbank.c:299
+            continue;
+        }
+
+        if (p.kind == SPEECH_MFCC)
+        {
+            for (int b = tid; b < B; b += NT) { mel[b] = floor_log(mel[b]); }   // c/kaldi_mfcc.c:318
+            __syncthreads();
+            for (int c = tid; c < C; c += NT)
+            {
+                const int cc = (c == C - 1 && C >= 2) ? C - 2 : c;         // c/kaldi_mfcc.c:333
+                const T *d = p.dct + (size_t)cc * B;
+                T acc = (T)0;
+                for (int b = 0; b < B; ++b) { acc += mel[b] * d[b]; }
+                T out = p.lift[cc] * acc;                                  // c/kaldi_mfcc.c:327-329
+                if (p.use_energy && cc == 0) { out = M<T>::log(rawe); }
+                y[c] = out;
+            }
+            continue;
+        }
+
+        // PLP tail
+        for (int j = tid; j < B + 2; j += NT)
+        {
+            const int b = (j == 0) ? 0 : ((j == B + 1) ? B - 1 : j - 1);
+            const T v = mel[b] * p.eql[b];
+            T cv;
+            if (p.compress_mode == 1) { cv = v; }
+            else if (p.compress_mode == 2) { cv = M<T>::sqrt(v); }
+            else { cv = M<T>::pow(v, p.compress); }
+            dup[j] = cv;
+        }
+        __syncthreads();
+        for (int i = tid; i <= P; i += NT)
+        {
+            const T *row = p.idft + (size_t)i * (B + 2);
+            T acc = (T)0;
+            for (int j = 0; j < B + 2; ++j) { acc += row[j] * dup[j]; }
+            ac[i] = acc;
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            T E = ac[0];
+            for (int i = 0; i < P; ++i)
+            {
+                T ki = ac[i + 1];
+                for (int j = 0; j < i; ++j) { ki += lpc[j] * ac[i - j]; }
+                ki = ki / E;
+                T c = (T)1 - ki * ki;
+                if (c < (T)1.0e-5) { c = (T)1.0e-5; }
+                E *= c;
+                tmp[i] = -ki;
+                for (int j = 0; j < i; ++j) { tmp[j] = lpc[j] - ki * lpc[i - j - 1]; }
+                for (int j = 0; j <= i; ++j) { lpc[j] = tmp[j]; }
+            }
+            for (int i = 0; i < P; ++i)
+            {
+                T sum = (T)0;
+                for (int j = 0; j < i; ++j) { sum += (T)(i - j) * lpc[j] * cep[i - j - 1]; }
+                cep[i] = -lpc[i] - sum / (T)(i + 1);
+            }
+            sc0[0] = floor_log(E);
+        }
+        __syncthreads();
+        for (int k = tid; k < C; k += NT)
+        {
+            const int kk = (k == C - 1 && C >= 2) ? C - 2 : k;
+            T v = (kk == 0) ? sc0[0] : ((kk - 1 < P) ? cep[kk - 1] : (T)0);
+            v *= p.lift[kk];
+            if (p.use_energy && kk == 0) { v = M<T>::log(rawe); }
+            y[k] = v;
+        }
+    }
+}
+
+// mn0: subtract the per-feature mean over the utterance's frames, D wide, summed last frame first
+// (intended behaviour of c/kaldi_fbank.c:355-370; see DESIGN.md "mn0").
+template <typename T>
+__global__ __launch_bounds__(NT) void mean_norm_kernel(const MeanNormParams p)
+{
+    const UttDesc utt = p.utts[blockIdx.x];
+    T *Y = reinterpret_cast<T *>(p.Y) + utt.y_off;
+    const long long W = (long long)utt.W;
+    for (int d = threadIdx.x; d < p.D; d += NT)
+    {
+        T s = (T)0;
+        for (long long w = W - 1; w >= 0; --w) { s += Y[w * p.D + d]; }
+        const T mn = s / (T)W;
+        for (long long w = 0; w < W; ++w) { Y[w * p.D + d] -= mn; }
+    }
+}
+
+template <typename T>
+hipError_t launch_generic(const FrameParams<T> &p, hipStream_t s)
+{
+    if (p.ntiles == 0) { return hipSuccess; }
+    const size_t lds = generic_lds_bytes(p.nfft, p.B, p.C, p.P, sizeof(T));
+    if (lds > 48 * 1024)   // opt in to large dynamic LDS on whichever device is current
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&generic_frames_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { return e; }
+    }
+    hipLaunchKernelGGL(generic_frames_kernel<T>, dim3(p.ntiles), dim3(NT), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t generic_lds_bytes(int nfft, int B, int C, int P, size_t elem)
+{
+    (void)C;
+    const size_t n = (size_t)2 * nfft + NT + (size_t)B + (size_t)(B + 2) + (size_t)4 * (P + 1) + 4;
+    return (n * elem + 15) & ~(size_t)15;
+}
+
+hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s) { return launch_generic<float>(p, s); }
+hipError_t launch_generic_f64(const FrameParams<double> &p, hipStream_t s) { return launch_generic<double>(p, s); }
+
+hipError_t launch_mean_norm_f32(const MeanNormParams &p, hipStream_t s)
+{
+    if (p.nutt == 0) { return hipSuccess; }
+    hipLaunchKernelGGL(mean_norm_kernel<float>, dim3(p.nutt), dim3(NT), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_mean_norm_f64(const MeanNormParams &p, hipStream_t s)
+{
+    if (p.nutt == 0) { return hipSuccess; }
+    hipLaunchKernelGGL(mean_norm_kernel<double>, dim3(p.nutt), dim3(NT), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace speech

@@ -1,0 +1,704 @@
+// speech_api.hip -- host layer of libspeech.so: option validation, per-plan tables, batch geometry,
+// launches, and the ten drop-in entry points of include/codee_speech.h.
+//
+// Tables are built on the host with the same libm calls and in the same precision as the
+// reference builds them per call (window c/kaldi_mfcc.c:105-135, mel c/kaldi_mfcc.c:157-188,
+// lifter c/kaldi_mfcc.c:200-210, equal loudness c/kaldi_plp.c:183-193), then kept on the device.
+// All arithmetic on audio happens in HIP kernels; there is no CPU fallback.
+#include "speech_internal.hpp"
+#include "../../include/codee_speech.h"
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <type_traits>
+
+#ifndef M_PI
+#define M_PI 3.141592653589793238462643383279502884
+#endif
+
+namespace speech {
+
+// fast-path hooks (fast_kernels.hip)
+struct FastTables;
+bool fast_supported(const speech_opts &o, size_t L, size_t nfft);
+int fast_tile_frames(const speech_opts &o);
+FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t stp, size_t nfft, size_t B, size_t C, size_t P,
+                               const std::vector<float> &win, const std::vector<float> &f2b, const std::vector<int> &beg,
+                               const std::vector<int> &num, const std::vector<float> &dct, const std::vector<float> &lift,
+                               const std::vector<float> &eql, const std::vector<float> &idft, std::string *err);
+void fast_tables_destroy(FastTables *t);
+size_t fast_scratch_elems(const FastTables *t, size_t total_frames);
+hipError_t launch_fast(const FastTables *t, const FrameParams<float> &p, float *scratch, hipStream_t s,
+                       hipEvent_t ev0, hipEvent_t ev1);
+
+static thread_local std::string g_err;
+
+static int fail(const char *fn, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = std::string("error in ") + fn + ": " + buf;
+    fprintf(stderr, "%s\n", g_err.c_str());
+    return 1;
+}
+
+static const char *kind_name(int kind, int dtype)
+{
+    static const char *names[4][2] = {{"kaldi_spectrogram_s", "kaldi_spectrogram_d"}, {"kaldi_fbank_s", "kaldi_fbank_d"},
+                                      {"kaldi_mfcc_s", "kaldi_mfcc_d"}, {"kaldi_plp_s", "kaldi_plp_d"}};
+    if (kind < 0 || kind > 3) { return "speech"; }
+    return names[kind][dtype == SPEECH_F64 ? 1 : 0];
+}
+
+struct Sizes { size_t L, stp, nfft, F, D; int log2n; };
+
+// Scalar validation and size derivation in the working precision: c/kaldi_mfcc.c:54-78 (and the same prologue
+// in c/kaldi_spectrogram.c:48-66, c/kaldi_fbank.c:61-82, c/kaldi_plp.c:55-79).
+template <typename T>
+static int validate(const speech_opts &o, Sizes *sz)
+{
+    const char *fn = kind_name(o.kind, o.dtype);
+    const T eps = std::is_same<T, float>::value ? (T)FLT_EPSILON : (T)DBL_EPSILON;
+    if (o.kind < 0 || o.kind > 3) { return fail("speech_plan_create", "unknown kind %d", o.kind); }
+    const T sr = (T)o.sr, fl = (T)o.frame_length, fs = (T)o.frame_shift;
+    if (!(sr >= eps)) { return fail(fn, "sr must be positive"); }
+    if (!(fl >= eps)) { return fail(fn, "frame_length must be positive"); }
+    if (!(fs >= eps)) { return fail(fn, "frame_shift must be positive"); }
+    if ((T)o.dither < (T)0) { return fail(fn, "dither must be nonnegative"); }
+    if ((T)o.preemph < (T)0) { return fail(fn, "preemph coeff must be nonnegative"); }
+    if (o.kind != SPEECH_SPECTROGRAM)
+    {
+        if ((T)o.lof < (T)0) { return fail(fn, "lof (low-freq cutoff) must be nonnegative"); }
+        if (!((T)o.hif > (T)o.lof)) { return fail(fn, "hif (high-freq cutoff) must be > lof"); }
+        if (o.B < 1u) { return fail(fn, "B (num mel bins) must be positive"); }
+    }
+    if (o.kind == SPEECH_MFCC || o.kind == SPEECH_PLP)
+    {
+        if (o.C < 1u) { return fail(fn, "C (num cepstral coeffs) must be positive"); }
+        if (o.C > o.B) { return fail(fn, "C (num cepstral coeffs) must be <= B (num mel bins)"); }
+        if ((T)o.Q < (T)0) { return fail(fn, "Q (lifter coeff) must be nonnegative"); }
+    }
+    const T Lf = sr * fl / (T)1000.0, Sf = sr * fs / (T)1000.0;
+    if (!(Lf < (T)2147483647.0) || !(Sf < (T)2147483647.0)) { return fail(fn, "frame_length/frame_shift too large (int-indexed, c/kaldi_mfcc.c:82-84)"); }
+    const size_t L = (size_t)Lf;
+    if (L < 1u) { return fail(fn, "frame_length must be greater than 1 sample"); }
+    const size_t stp = (size_t)Sf;
+    if (stp < 1u) { return fail(fn, "frame_shift must be greater than 1 sample"); }
+    if (L < 3u) { return fail(fn, "frame_length must be at least 3 samples"); }     // defined divergence, DESIGN.md "edge cases"
+    size_t nfft = 1u; int lg2 = 0;
+    while (nfft < L) { nfft *= 2u; ++lg2; }
+    if (nfft > (size_t)GENERIC_MAX_NFFT) { return fail(fn, "frame_length of %zu samples needs a %zu-point FFT; this build supports up to %d", L, nfft, GENERIC_MAX_NFFT); }
+    if (o.B > 4096u) { return fail(fn, "B (num mel bins) above 4096 is not supported"); }
+    sz->L = L; sz->stp = stp; sz->nfft = nfft; sz->F = nfft / 2u + 1u; sz->log2n = lg2;
+    if (o.kind == SPEECH_SPECTROGRAM) { sz->D = sz->F; }
+    else if (o.kind == SPEECH_FBANK) { sz->D = o.B + (o.use_energy ? 1u : 0u); }
+    else { sz->D = o.C; }
+    return 0;
+}
+
+static int window_known(const char *w)
+{
+    return strncmp(w, "rectangular", 11u) == 0 || strncmp(w, "blackman", 8u) == 0 || strncmp(w, "hamming", 7u) == 0 ||
+           strncmp(w, "hann", 4u) == 0 || strncmp(w, "povey", 5u) == 0;
+}
+
+template <typename T> struct HM;
+template <> struct HM<float> {
+    static float cos(float x) { return cosf(x); } static float sin(float x) { return sinf(x); }
+    static float log(float x) { return logf(x); } static float exp(float x) { return expf(x); }
+    static float pow(float x, float y) { return powf(x, y); } static float sqrt(float x) { return sqrtf(x); }
+};
+template <> struct HM<double> {
+    static double cos(double x) { return ::cos(x); } static double sin(double x) { return ::sin(x); }
+    static double log(double x) { return ::log(x); } static double exp(double x) { return ::exp(x); }
+    static double pow(double x, double y) { return ::pow(x, y); } static double sqrt(double x) { return ::sqrt(x); }
+};
+
+template <typename T>
+struct HostTables {
+    std::vector<T> win, twr, twi, f2b, dct, lift, eql, idft;
+    std::vector<int> beg, num, off;
+};
+
+template <typename T>
+static void build_tables(const speech_opts &o, const Sizes &sz, size_t P, HostTables<T> *t)
+{
+    const size_t L = sz.L, nfft = sz.nfft, F = sz.F, B = o.B, C = o.C;
+    // window: c/kaldi_mfcc.c:105-135 (prefix match in this order)
+    t->win.resize(L);
+    const char *wt = o.win_type;
+    if (strncmp(wt, "rectangular", 11u) == 0) { for (size_t l = 0; l < L; ++l) { t->win[l] = (T)1; } }
+    else
+    {
+        const T a = std::is_same<T, float>::value ? (T)(float)(2.0 * M_PI / (double)(L - 1u)) : (T)(2.0 * M_PI / (double)(L - 1u));
+        if (strncmp(wt, "blackman", 8u) == 0)
+        {
+            const T coeff = (T)0.42, coeff1 = (T)1 - coeff;       // sic: c/kaldi_mfcc.c:116
+            for (size_t l = 0; l < L; ++l) { t->win[l] = coeff - (T)0.5 * HM<T>::cos((T)l * a) + coeff1 * HM<T>::cos((T)(2u * l) * a); }
+        }
+        else if (strncmp(wt, "hamming", 7u) == 0) { for (size_t l = 0; l < L; ++l) { t->win[l] = (T)0.54 - (T)0.46 * HM<T>::cos((T)l * a); } }
+        else if (strncmp(wt, "hann", 4u) == 0) { for (size_t l = 0; l < L; ++l) { t->win[l] = (T)0.5 - (T)0.5 * HM<T>::cos((T)l * a); } }
+        else { for (size_t l = 0; l < L; ++l) { t->win[l] = HM<T>::pow((T)0.5 - (T)0.5 * HM<T>::cos((T)l * a), (T)0.85); } }
+    }
+    // twiddles of the generic radix-2 FFT
+    t->twr.resize(nfft / 2u); t->twi.resize(nfft / 2u);
+    for (size_t k = 0; k < nfft / 2u; ++k)
+    {
+        const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)k / (long double)nfft;
+        t->twr[k] = (T)cosl(ang); t->twi[k] = (T)sinl(ang);
+    }
+    if (o.kind == SPEECH_SPECTROGRAM) { return; }
+
+    // sparse mel table: c/kaldi_mfcc.c:157-188
+    const T sr = (T)o.sr, lof = (T)o.lof, hif = (T)o.hif;
+    const T finc = sr / (T)nfft;
+    const T lomel = (T)1127.0 * HM<T>::log((T)1 + lof / (T)700.0);
+    const T himel = (T)1127.0 * HM<T>::log((T)1 + hif / (T)700.0);
+    const T dmel = (himel - lomel) / (T)(B + 1u);
+    std::vector<T> mels(F);
+    for (size_t f = 0; f < F; ++f) { mels[f] = (T)1127.0 * HM<T>::log((T)1 + (T)f * finc / (T)700.0); }
+    T lmel = lomel, cmel = lmel + dmel, rmel = cmel + dmel;
+    t->beg.resize(B); t->num.resize(B); t->off.resize(B);
+    for (size_t b = B; b > 0u; --b)
+    {
+        const size_t i = B - b;
+        size_t f = 0u;
+        while (f < F && mels[f] < lmel) { ++f; }
+        t->beg[i] = (int)f; t->off[i] = (int)t->f2b.size();
+        while (f < F && mels[f] < cmel) { t->f2b.push_back((mels[f] - lmel) / dmel); ++f; }
+        while (f < F && mels[f] < rmel) { t->f2b.push_back((rmel - mels[f]) / dmel); ++f; }
+        t->num[i] = (int)f - t->beg[i];
+        lmel = cmel; cmel = rmel;
+        rmel = (b == 2u) ? himel : rmel + dmel;
+    }
+    if (t->f2b.empty()) { t->f2b.push_back((T)0); }
+
+    if (o.kind == SPEECH_MFCC)
+    {
+        // lifter with folded DCT scaling: c/kaldi_mfcc.c:200-210
+        t->lift.resize(C);
+        const T Q = (T)o.Q;
+        const T sc = (T)1 / HM<T>::sqrt((T)(2u * B));
+        if (Q > (T)FLT_EPSILON) { for (size_t c = 0; c < C; ++c) { t->lift[c] = (T)1 + (T)0.5 * Q * HM<T>::sin((T)M_PI * (T)c / Q); } }
+        else { for (size_t c = 0; c < C; ++c) { t->lift[c] = (T)1; } }
+        for (size_t c = 1; c < C; ++c) { t->lift[c] *= sc; }
+        t->lift[0] *= (T)0.5 / HM<T>::sqrt((T)B);
+        // FFTW REDFT10 as a matrix (plan at c/kaldi_mfcc.c:195): Yd[k] = 2 sum_n Xd[n] cos(pi (n+1/2) k / B)
+        t->dct.resize(C * B);
+        for (size_t c = 0; c < C; ++c) { for (size_t b = 0; b < B; ++b) {
+            t->dct[c * B + b] = (T)(2.0L * cosl(3.141592653589793238462643383279502884L * ((long double)b + 0.5L) * (long double)c / (long double)B)); } }
+    }
+    if (o.kind == SPEECH_PLP)
+    {
+        // equal loudness: c/kaldi_plp.c:183-193
+        t->eql.resize(B);
+        T cm = lomel + dmel;
+        for (size_t b = 0; b < B; ++b, cm += dmel)
+        {
+            const T cf = (T)700.0 * (HM<T>::exp(cm / (T)1127.0) - (T)1);
+            const T fsq = cf * cf;
+            const T fsub = fsq / (fsq + (T)160000.0);
+            t->eql[b] = fsub * fsub * ((fsq + (T)1440000.0) / (fsq + (T)9610000.0));
+        }
+        // Kaldi idft bases
+        t->idft.resize((P + 1u) * (B + 2u));
+        const T angle = (T)M_PI / (T)(B + 1u);
+        const T scale = (T)1 / ((T)2 * (T)(B + 1u));
+        for (size_t i = 0; i <= P; ++i)
+        {
+            t->idft[i * (B + 2u)] = scale;
+            for (size_t j = 1; j <= B; ++j) { t->idft[i * (B + 2u) + j] = (T)2 * scale * HM<T>::cos(angle * (T)i * (T)j); }
+            t->idft[i * (B + 2u) + B + 1u] = scale * HM<T>::cos(angle * (T)i * (T)(B + 1u));
+        }
+        t->lift.resize(C);
+        const T Q = (T)o.Q, cs = (T)o.cep_scale;
+        if (Q > (T)FLT_EPSILON) { for (size_t c = 0; c < C; ++c) { t->lift[c] = ((T)1 + (T)0.5 * Q * HM<T>::sin((T)M_PI * (T)c / Q)) * cs; } }
+        else { for (size_t c = 0; c < C; ++c) { t->lift[c] = cs; } }
+    }
+}
+
+}  // namespace speech
+
+using namespace speech;
+
+struct speech_plan {
+    speech_opts o;
+    int device;
+    Sizes sz;
+    size_t P;
+    bool tuned;
+    std::vector<void *> dev_allocs;
+    void *d_win, *d_twr, *d_twi, *d_f2b, *d_dct, *d_lift, *d_eql, *d_idft;
+    int *d_beg, *d_num, *d_off;
+    FastTables *fast;
+};
+
+struct speech_batch {
+    speech_plan *plan;
+    std::vector<UttDesc> utts;
+    std::vector<TileDesc> tiles;
+    UttDesc *d_utts;
+    TileDesc *d_tiles;
+    float *d_scratch;
+    size_t total_samples, total_out, total_frames;
+    hipEvent_t ev0, ev1;
+};
+
+namespace {
+
+#define HIP_TRY(fn, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) { return fail(fn, "HIP call failed: %s (%s)", #expr, hipGetErrorString(e_)); } \
+    } while (0)
+
+struct DeviceGuard {
+    int prev; bool ok;
+    explicit DeviceGuard(int dev) : prev(-1), ok(false)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() { if (prev >= 0) { (void)hipSetDevice(prev); } }
+};
+
+template <typename V>
+int upload(speech_plan *p, const std::vector<V> &h, void **d)
+{
+    *d = nullptr;
+    if (h.empty()) { return 0; }
+    HIP_TRY("speech_plan_create", hipMalloc(d, h.size() * sizeof(V)));
+    p->dev_allocs.push_back(*d);
+    HIP_TRY("speech_plan_create", hipMemcpy(*d, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename T>
+int plan_build(speech_plan *p)
+{
+    HostTables<T> t;
+    build_tables<T>(p->o, p->sz, p->P, &t);
+    if (upload(p, t.win, &p->d_win) || upload(p, t.twr, &p->d_twr) || upload(p, t.twi, &p->d_twi) || upload(p, t.f2b, &p->d_f2b) ||
+        upload(p, t.dct, &p->d_dct) || upload(p, t.lift, &p->d_lift) || upload(p, t.eql, &p->d_eql) || upload(p, t.idft, &p->d_idft) ||
+        upload(p, t.beg, (void **)&p->d_beg) || upload(p, t.num, (void **)&p->d_num) || upload(p, t.off, (void **)&p->d_off)) { return 1; }
+    return 0;
+}
+
+template <>
+int plan_build<float>(speech_plan *p)
+{
+    HostTables<float> t;
+    build_tables<float>(p->o, p->sz, p->P, &t);
+    if (upload(p, t.win, &p->d_win) || upload(p, t.twr, &p->d_twr) || upload(p, t.twi, &p->d_twi) || upload(p, t.f2b, &p->d_f2b) ||
+        upload(p, t.dct, &p->d_dct) || upload(p, t.lift, &p->d_lift) || upload(p, t.eql, &p->d_eql) || upload(p, t.idft, &p->d_idft) ||
+        upload(p, t.beg, (void **)&p->d_beg) || upload(p, t.num, (void **)&p->d_num) || upload(p, t.off, (void **)&p->d_off)) { return 1; }
+    p->tuned = false; p->fast = nullptr;
+    if (!p->o.force_generic && fast_supported(p->o, p->sz.L, p->sz.nfft))
+    {
+        std::string err;
+        p->fast = fast_tables_create(p->o, p->sz.L, p->sz.stp, p->sz.nfft, p->o.B, p->o.C, p->P, t.win, t.f2b, t.beg, t.num, t.dct, t.lift, t.eql, t.idft, &err);
+        if (!p->fast) { return fail("speech_plan_create", "tuned-kernel tables: %s", err.c_str()); }
+        p->tuned = true;
+    }
+    return 0;
+}
+
+template <typename T>
+void fill_params(const speech_batch *b, const void *X, void *Y, FrameParams<T> *fp)
+{
+    const speech_plan *p = b->plan;
+    const speech_opts &o = p->o;
+    memset(fp, 0, sizeof(*fp));
+    fp->X = (const T *)X; fp->Y = (T *)Y;
+    fp->utts = b->d_utts; fp->tiles = b->d_tiles; fp->ntiles = (uint32_t)b->tiles.size();
+    fp->kind = o.kind;
+    fp->L = (int)p->sz.L; fp->stp = (int)p->sz.stp; fp->nfft = (int)p->sz.nfft; fp->F = (int)p->sz.F; fp->log2n = p->sz.log2n;
+    fp->D = (int)p->sz.D;
+    fp->snip_edges = o.snip_edges ? 1 : 0; fp->dc0 = o.dc0 ? 1 : 0; fp->raw_energy = o.raw_energy ? 1 : 0;
+    fp->use_energy = o.use_energy ? 1 : 0; fp->amp = o.amp ? 1 : 0; fp->lg = o.lg ? 1 : 0;
+    const bool spec = (o.kind == SPEECH_SPECTROGRAM);
+    fp->want_pre = spec ? (o.raw_energy ? 1 : 0) : ((o.use_energy && o.raw_energy) ? 1 : 0);     // c/kaldi_spectrogram.c:203 vs c/kaldi_mfcc.c:274
+    fp->want_post = spec ? (o.raw_energy ? 0 : 1) : ((o.use_energy && !o.raw_energy) ? 1 : 0);   // c/kaldi_spectrogram.c:224 vs c/kaldi_mfcc.c:295
+    fp->pre_before_dc = (o.dtype == SPEECH_F64 && o.kind == SPEECH_MFCC) ? 1 : 0;                // c/kaldi_mfcc.c:576-591
+    fp->preemph = (T)o.preemph; fp->dither = (T)o.dither;
+    fp->do_preemph = !(p->sz.L < 2u || (T)o.preemph < (T)FLT_EPSILON);                           // c/kaldi_mfcc.c:282
+    fp->do_dither = ((T)o.dither > (T)FLT_EPSILON);                                              // c/kaldi_mfcc.c:243
+    fp->seed = o.dither_seed;
+    fp->win = (const T *)p->d_win; fp->tw_re = (const T *)p->d_twr; fp->tw_im = (const T *)p->d_twi;
+    fp->B = spec ? 0 : (int)o.B;
+    fp->f2b = (const T *)p->d_f2b; fp->mel_beg = p->d_beg; fp->mel_num = p->d_num; fp->mel_off = p->d_off;
+    fp->C = (o.kind == SPEECH_MFCC || o.kind == SPEECH_PLP) ? (int)o.C : 0;
+    fp->dct = (const T *)p->d_dct; fp->lift = (const T *)p->d_lift;
+    fp->P = (o.kind == SPEECH_PLP) ? (int)p->P : 0;
+    fp->compress = (T)o.compress;
+    fp->compress_mode = ((T)o.compress == (T)1) ? 1 : (((T)o.compress == (T)0.5) ? 2 : 0);       // c/kaldi_plp.c:341,347
+    fp->eql = (const T *)p->d_eql; fp->idft = (const T *)p->d_idft;
+    fp->mel_out = nullptr;
+}
+
+int batch_run(speech_batch *b, const void *X, void *Y, void *stream, float *kernel_ms)
+{
+    const char *fn = "speech_batch_run";
+    if (!b || !b->plan) { return fail(fn, "null batch"); }
+    speech_plan *p = b->plan;
+    if (b->tiles.empty()) { if (kernel_ms) { *kernel_ms = 0.0f; } return 0; }
+    if (!X || !Y) { return fail(fn, "null device pointer"); }
+    DeviceGuard g(p->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", p->device); }
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (kernel_ms)
+    {
+        if (!b->ev0) { HIP_TRY(fn, hipEventCreate(&b->ev0)); HIP_TRY(fn, hipEventCreate(&b->ev1)); }
+        e0 = b->ev0; e1 = b->ev1;
+    }
+    if (p->o.dtype == SPEECH_F64)
+    {
+        FrameParams<double> fp; fill_params<double>(b, X, Y, &fp);
+        if (e0) { HIP_TRY(fn, hipEventRecord(e0, s)); }
+        HIP_TRY(fn, launch_generic_f64(fp, s));
+        if (e1) { HIP_TRY(fn, hipEventRecord(e1, s)); }
+    }
+    else
+    {
+        FrameParams<float> fp; fill_params<float>(b, X, Y, &fp);
+        if (p->tuned) { HIP_TRY(fn, launch_fast(p->fast, fp, b->d_scratch, s, e0, e1)); }
+        else
+        {
+            if (e0) { HIP_TRY(fn, hipEventRecord(e0, s)); }
+            HIP_TRY(fn, launch_generic_f32(fp, s));
+            if (e1) { HIP_TRY(fn, hipEventRecord(e1, s)); }
+        }
+    }
+    if (p->o.mn0)
+    {
+        MeanNormParams mp; mp.Y = Y; mp.utts = b->d_utts; mp.nutt = (uint32_t)b->utts.size(); mp.D = (int)p->sz.D;
+        HIP_TRY(fn, p->o.dtype == SPEECH_F64 ? launch_mean_norm_f64(mp, s) : launch_mean_norm_f32(mp, s));
+    }
+    if (kernel_ms)
+    {
+        HIP_TRY(fn, hipEventSynchronize(e1));
+        HIP_TRY(fn, hipStreamSynchronize(s));
+        HIP_TRY(fn, hipEventElapsedTime(kernel_ms, e0, e1));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void speech_opts_default(speech_opts *o, int kind)
+{
+    memset(o, 0, sizeof(*o));
+    o->kind = kind; o->dtype = SPEECH_F32;
+    o->sr = 16000.0; o->frame_length = 25.0; o->frame_shift = 10.0;        // srci/kaldi_mfcc.cpp:106-115
+    o->snip_edges = 0; o->dither = 0.0; o->dc0 = 0; o->raw_energy = 0;     // srci/kaldi_mfcc.cpp:118-128 (CLI dither default is 0.1)
+    o->preemph = 0.97; strcpy(o->win_type, "povey");                       // srci/kaldi_mfcc.cpp:131-135
+    o->amp = 0; o->lof = 20.0; o->hif = 8000.0; o->B = 23; o->lg = 1;      // srci/kaldi_mfcc.cpp:144-156 (hif = Nyquist)
+    o->use_energy = 0; o->C = 13; o->Q = 22.0;                             // srci/kaldi_mfcc.cpp:159-169
+    o->compress = 1.0 / 3.0; o->cep_scale = 1.0; o->lpc_order = 0; o->mn0 = 0;
+    o->dither_seed = 0x5EED2026ull; o->force_generic = 0;
+}
+
+int speech_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { return 0; }
+    return n;
+}
+
+const char *speech_last_error(void) { return g_err.c_str(); }
+
+int speech_plan_create(speech_plan **out, const speech_opts *opts, int device)
+{
+    const char *fn = "speech_plan_create";
+    if (!out || !opts) { return fail(fn, "null argument"); }
+    *out = nullptr;
+    speech_opts o = *opts;
+    o.win_type[sizeof(o.win_type) - 1] = '\0';
+    Sizes sz;
+    if (o.dtype == SPEECH_F64 ? validate<double>(o, &sz) : validate<float>(o, &sz)) { return 1; }
+    if (!window_known(o.win_type))
+    {
+        return fail(kind_name(o.kind, o.dtype), "window type must be rectangular, blackman, hamming, hann or povey (lower-cased)");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { return fail(fn, "no HIP device available (this library has no CPU fallback)"); }
+    if (device < 0 || device >= ndev) { return fail(fn, "device %d out of range (0..%d)", device, ndev - 1); }
+    speech_plan *p = new (std::nothrow) speech_plan();
+    if (!p) { return fail(fn, "out of host memory"); }
+    p->o = o; p->device = device; p->sz = sz; p->tuned = false; p->fast = nullptr;
+    p->P = (o.kind == SPEECH_PLP) ? ((o.lpc_order > 0u) ? o.lpc_order : o.C - 1u) : 0u;     // order = C-1
+    p->d_win = p->d_twr = p->d_twi = p->d_f2b = p->d_dct = p->d_lift = p->d_eql = p->d_idft = nullptr;
+    p->d_beg = p->d_num = p->d_off = nullptr;
+    if (p->P > 256u) { delete p; return fail(fn, "lpc_order above 256 is not supported"); }
+    DeviceGuard g(device);
+    if (!g.ok) { delete p; return fail(fn, "cannot select device %d", device); }
+    const int rc = (o.dtype == SPEECH_F64) ? plan_build<double>(p) : plan_build<float>(p);
+    if (rc) { speech_plan_destroy(p); return 1; }
+    if (!p->tuned)
+    {
+        const size_t lds = generic_lds_bytes((int)sz.nfft, (int)o.B, (int)o.C, (int)p->P, o.dtype == SPEECH_F64 ? 8 : 4);
+        if (lds > 160u * 1024u) { speech_plan_destroy(p); return fail(fn, "frame of %zu samples does not fit in LDS (%zu bytes needed)", sz.L, lds); }
+    }
+    *out = p;
+    return 0;
+}
+
+void speech_plan_destroy(speech_plan *p)
+{
+    if (!p) { return; }
+    DeviceGuard g(p->device);
+    for (void *d : p->dev_allocs) { (void)hipFree(d); }
+    if (p->fast) { fast_tables_destroy(p->fast); }
+    delete p;
+}
+
+int speech_plan_sizes(const speech_plan *p, size_t *L, size_t *stp, size_t *nfft, size_t *D, int *tuned)
+{
+    if (!p) { return fail("speech_plan_sizes", "null plan"); }
+    if (L) { *L = p->sz.L; } if (stp) { *stp = p->sz.stp; } if (nfft) { *nfft = p->sz.nfft; } if (D) { *D = p->sz.D; }
+    if (tuned) { *tuned = p->tuned ? 1 : 0; }
+    return 0;
+}
+
+int speech_plan_num_frames(const speech_plan *p, size_t N, size_t *W)
+{
+    if (W) { *W = 0; }
+    if (!p) { return 1; }
+    if (N < 1u || N > 2147483647u) { return 1; }                       // int-indexed in the reference: c/kaldi_mfcc.c:82-84
+    if (p->o.snip_edges && p->sz.L > N) { return 1; }                  // c/kaldi_mfcc.c:70
+    const size_t w = p->o.snip_edges ? 1u + (N - p->sz.L) / p->sz.stp : (N + p->sz.stp / 2u) / p->sz.stp;   // c/kaldi_mfcc.c:77
+    if (W) { *W = w; }
+    return 0;
+}
+
+int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off)
+{
+    const char *fn = "speech_batch_create";
+    if (!out || !p || (nutt && !n_samples)) { return fail(fn, "null argument"); }
+    *out = nullptr;
+    if (nutt > 0xFFFFFFFFull) { return fail(fn, "too many utterances"); }
+    speech_batch *b = new (std::nothrow) speech_batch();
+    if (!b) { return fail(fn, "out of host memory"); }
+    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_scratch = nullptr; b->ev0 = b->ev1 = nullptr;
+    b->total_samples = b->total_out = b->total_frames = 0;
+    const int tile = p->tuned ? fast_tile_frames(p->o) : GENERIC_TILE_FRAMES;
+    const char *kfn = kind_name(p->o.kind, p->o.dtype);
+    b->utts.resize(nutt);
+    size_t xo = 0, yo = 0;
+    for (size_t u = 0; u < nutt; ++u)
+    {
+        const size_t N = n_samples[u];
+        size_t W = 0;
+        if (N < 1u) { delete b; return fail(kfn, "N (nsamps in signal) must be positive"); }
+        if (p->o.snip_edges && p->sz.L > N) { delete b; return fail(kfn, "frame length must be < signal length if snip_edges"); }
+        if (speech_plan_num_frames(p, N, &W)) { delete b; return fail(kfn, "utterance %zu: %zu samples not supported (int-indexed)", u, N); }
+        UttDesc d;
+        d.x_off = x_off ? x_off[u] : xo; d.n = N; d.y_off = y_off ? y_off[u] : yo; d.W = W;
+        b->utts[u] = d;
+        xo += N; yo += W * p->sz.D;
+        b->total_samples += N; b->total_out += W * p->sz.D; b->total_frames += W;
+        for (size_t f0 = 0; f0 < W; f0 += (size_t)tile)
+        {
+            TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.pad = 0;
+            b->tiles.push_back(t);
+        }
+    }
+    if (b->tiles.size() > 0x7FFFFFFFull) { delete b; return fail(fn, "batch too large for one launch (%zu tiles)", b->tiles.size()); }
+    DeviceGuard g(p->device);
+    if (!g.ok) { delete b; return fail(fn, "cannot select device %d", p->device); }
+    hipError_t e = hipSuccess;
+    if (nutt) { e = hipMalloc((void **)&b->d_utts, nutt * sizeof(UttDesc)); }
+    if (e == hipSuccess && nutt) { e = hipMemcpy(b->d_utts, b->utts.data(), nutt * sizeof(UttDesc), hipMemcpyHostToDevice); }
+    if (e == hipSuccess && !b->tiles.empty()) { e = hipMalloc((void **)&b->d_tiles, b->tiles.size() * sizeof(TileDesc)); }
+    if (e == hipSuccess && !b->tiles.empty()) { e = hipMemcpy(b->d_tiles, b->tiles.data(), b->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice); }
+    if (e == hipSuccess && p->tuned)
+    {
+        const size_t ns = fast_scratch_elems(p->fast, b->total_frames);
+        if (ns) { e = hipMalloc((void **)&b->d_scratch, ns * sizeof(float)); }
+    }
+    if (e != hipSuccess) { speech_batch_destroy(b); return fail(fn, "device allocation failed: %s", hipGetErrorString(e)); }
+    *out = b;
+    return 0;
+}
+
+void speech_batch_destroy(speech_batch *b)
+{
+    if (!b) { return; }
+    DeviceGuard g(b->plan ? b->plan->device : 0);
+    if (b->d_utts) { (void)hipFree(b->d_utts); }
+    if (b->d_tiles) { (void)hipFree(b->d_tiles); }
+    if (b->d_scratch) { (void)hipFree(b->d_scratch); }
+    if (b->ev0) { (void)hipEventDestroy(b->ev0); }
+    if (b->ev1) { (void)hipEventDestroy(b->ev1); }
+    delete b;
+}
+
+int speech_batch_totals(const speech_batch *b, size_t *total_samples, size_t *total_out, size_t *total_frames)
+{
+    if (!b) { return fail("speech_batch_totals", "null batch"); }
+    if (total_samples) { *total_samples = b->total_samples; }
+    if (total_out) { *total_out = b->total_out; }
+    if (total_frames) { *total_frames = b->total_frames; }
+    return 0;
+}
+
+int speech_batch_offsets(const speech_batch *b, size_t *x_off, size_t *y_off, size_t *n_frames)
+{
+    if (!b) { return fail("speech_batch_offsets", "null batch"); }
+    for (size_t u = 0; u < b->utts.size(); ++u)
+    {
+        if (x_off) { x_off[u] = (size_t)b->utts[u].x_off; }
+        if (y_off) { y_off[u] = (size_t)b->utts[u].y_off; }
+        if (n_frames) { n_frames[u] = (size_t)b->utts[u].W; }
+    }
+    return 0;
+}
+
+int speech_batch_run(speech_batch *b, const void *X, void *Y, void *stream) { return batch_run(b, X, Y, stream, nullptr); }
+
+int speech_batch_run_timed(speech_batch *b, const void *X, void *Y, void *stream, float *kernel_ms)
+{
+    if (!kernel_ms) { return fail("speech_batch_run_timed", "null kernel_ms"); }
+    return batch_run(b, X, Y, stream, kernel_ms);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The ten drop-in entry points (include/codee_speech.h).  Host pointers in, host pointers out.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+int legacy_call(speech_opts &o, T *Y, const T *X, size_t N)
+{
+    const char *fn = kind_name(o.kind, o.dtype);
+    if (N < 1u) { return fail(fn, "N (nsamps in signal) must be positive"); }                 // c/kaldi_mfcc.c:54
+    Sizes sz;
+    if (validate<T>(o, &sz)) { return 1; }
+    if (o.snip_edges && sz.L > N) { return fail(fn, "frame length must be < signal length if snip_edges"); }   // c/kaldi_mfcc.c:70
+    if (N > 2147483647u) { return fail(fn, "N above 2^31-1 is not supported (int-indexed, c/kaldi_mfcc.c:82-84)"); }
+    const size_t W = o.snip_edges ? 1u + (N - sz.L) / sz.stp : (N + sz.stp / 2u) / sz.stp;     // c/kaldi_mfcc.c:77
+    if (W == 0u) { return 0; }                                                                 // c/kaldi_mfcc.c:78
+    if (!X || !Y) { return fail(fn, "null pointer"); }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { return fail(fn, "no HIP device available (this library has no CPU fallback)"); }
+    speech_plan *p = nullptr; speech_batch *b = nullptr;
+    if (speech_plan_create(&p, &o, dev)) { return 1; }
+    int rc = 1;
+    void *dX = nullptr, *dY = nullptr;
+    const size_t nout = W * sz.D;
+    do
+    {
+        if (speech_batch_create(&b, p, 1u, &N, nullptr, nullptr)) { break; }
+        if (hipMalloc(&dX, N * sizeof(T)) != hipSuccess || hipMalloc(&dY, nout * sizeof(T)) != hipSuccess) { fail(fn, "problem with hipMalloc"); break; }
+        if (hipMemcpy(dX, X, N * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { fail(fn, "problem copying X to the device"); break; }
+        if (speech_batch_run(b, dX, dY, nullptr)) { break; }
+        hipError_t e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) { fail(fn, "kernel execution failed: %s", hipGetErrorString(e)); break; }
+        if (hipMemcpy(Y, dY, nout * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) { fail(fn, "problem copying Y from the device"); break; }
+        rc = 0;
+    } while (0);
+    if (dX) { (void)hipFree(dX); }
+    if (dY) { (void)hipFree(dY); }
+    if (b) { speech_batch_destroy(b); }
+    speech_plan_destroy(p);
+    return rc;
+}
+
+template <typename T>
+void front(speech_opts &o, int kind, T sr, T fl, T fs, int snip, T dither, int dc0, int raw_energy, T preemph, const char *win, int mn0)
+{
+    speech_opts_default(&o, kind);
+    o.dtype = std::is_same<T, double>::value ? SPEECH_F64 : SPEECH_F32;
+    o.sr = (double)sr; o.frame_length = (double)fl; o.frame_shift = (double)fs; o.snip_edges = snip; o.dither = (double)dither;
+    o.dc0 = dc0; o.raw_energy = raw_energy; o.preemph = (double)preemph; o.mn0 = mn0;
+    strncpy(o.win_type, win ? win : "", sizeof(o.win_type) - 1); o.win_type[sizeof(o.win_type) - 1] = '\0';
+}
+
+}  // namespace
+
+namespace codee {
+extern "C" {
+
+int kaldi_spectrogram_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const int mn0)
+{
+    speech_opts o; front<float>(o, SPEECH_SPECTROGRAM, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    return legacy_call<float>(o, Y, X, N);
+}
+
+int kaldi_spectrogram_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const int mn0)
+{
+    speech_opts o; front<double>(o, SPEECH_SPECTROGRAM, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    return legacy_call<double>(o, Y, X, N);
+}
+
+int kaldi_fbank_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const int amp, const float lof, const float hif, const size_t B, const int lg, const int use_energy, const int mn0)
+{
+    speech_opts o; front<float>(o, SPEECH_FBANK, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    o.amp = amp; o.lof = (double)lof; o.hif = (double)hif; o.B = B; o.lg = lg; o.use_energy = use_energy;
+    return legacy_call<float>(o, Y, X, N);
+}
+
+int kaldi_fbank_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const int amp, const double lof, const double hif, const size_t B, const int lg, const int use_energy, const int mn0)
+{
+    speech_opts o; front<double>(o, SPEECH_FBANK, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    o.amp = amp; o.lof = lof; o.hif = hif; o.B = B; o.lg = lg; o.use_energy = use_energy;
+    return legacy_call<double>(o, Y, X, N);
+}
+
+// The reference's *_default_* functions hard-wire sr=16000, frame_length=25 ms, B=80 and, as written, do not
+// work (c/kaldi_fbank.c:36-37; frames stored reversed at :786,804).  Exported for ABI completeness as the
+// general path with those constants; parity unpinned.
+int kaldi_fbank_default_s(float *Y, float *X, const size_t N, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const int amp, const float lof, const float hif, const int lg, const int use_energy, const int mn0)
+{
+    return kaldi_fbank_s(Y, X, N, 16000.0f, 25.0f, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, amp, lof, hif, 80u, lg, use_energy, mn0);
+}
+
+int kaldi_fbank_default_d(double *Y, double *X, const size_t N, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const int amp, const double lof, const double hif, const int lg, const int use_energy, const int mn0)
+{
+    return kaldi_fbank_d(Y, X, N, 16000.0, 25.0, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, amp, lof, hif, 80u, lg, use_energy, mn0);
+}
+
+int kaldi_mfcc_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const float lof, const float hif, const size_t B, const size_t C, const float Q, const int use_energy, const int mn0)
+{
+    speech_opts o; front<float>(o, SPEECH_MFCC, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    o.lof = (double)lof; o.hif = (double)hif; o.B = B; o.C = C; o.Q = (double)Q; o.use_energy = use_energy;
+    return legacy_call<float>(o, Y, X, N);
+}
+
+int kaldi_mfcc_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const double lof, const double hif, const size_t B, const size_t C, const double Q, const int use_energy, const int mn0)
+{
+    speech_opts o; front<double>(o, SPEECH_MFCC, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    o.lof = lof; o.hif = hif; o.B = B; o.C = C; o.Q = Q; o.use_energy = use_energy;
+    return legacy_call<double>(o, Y, X, N);
+}
+
+int kaldi_plp_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const float lof, const float hif, const size_t B, const float compress, const size_t C, const float Q, const float cep_scale, const int use_energy, const int mn0)
+{
+    speech_opts o; front<float>(o, SPEECH_PLP, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    o.lof = (double)lof; o.hif = (double)hif; o.B = B; o.C = C; o.Q = (double)Q; o.use_energy = use_energy;
+    o.compress = (double)compress; o.cep_scale = (double)cep_scale; o.lpc_order = 0;
+    return legacy_call<float>(o, Y, X, N);
+}
+
+int kaldi_plp_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const double lof, const double hif, const size_t B, const double compress, const size_t C, const double Q, const double cep_scale, const int use_energy, const int mn0)
+{
+    speech_opts o; front<double>(o, SPEECH_PLP, sr, frame_length, frame_shift, snip_edges, dither, dc0, raw_energy, preemph, win_type, mn0);
+    o.lof = lof; o.hif = hif; o.B = B; o.C = C; o.Q = Q; o.use_energy = use_energy;
+    o.compress = compress; o.cep_scale = cep_scale; o.lpc_order = 0;
+    return legacy_call<double>(o, Y, X, N);
+}
+
+}  // extern "C"
+}  // namespace codee

@@ -1,0 +1,84 @@
+"""Option grid shared by the CPU tests (oracle vs numpy truth) and the GPU parity tests (HIP vs oracle).
+Follows SURVEY.md 8(c): snip_edges x dc0 x raw_energy x use_energy x window x preemph x (B,C,Q) x amp/lg x lengths x sr."""
+import itertools
+
+WINDOWS = ["rectangular", "blackman", "hamming", "hann", "povey"]
+
+# (kind, N, seed, opts)
+GRID = []
+
+
+def _add(kind, N, seed, **o):
+    GRID.append((kind, N, seed, o))
+
+
+# BASELINE.json configs at reduced length (1 s) -- the full sizes run in the GPU tests through properties
+_add("mfcc", 16000, 1, snip=1)                                   # config 1
+_add("mfcc", 16000, 1, snip=0)
+_add("spectrogram", 16000, 2, snip=1)                            # config 2
+_add("fbank", 16000, 3, B=80)                                    # config 3
+_add("mfcc", 16000, 4, B=40, C=40, hif=7600.0)                   # config 4 (hires)
+_add("plp", 16000, 5)                                            # config 5
+
+# front-end flag grid on a short signal
+for kind in ("spectrogram", "fbank", "mfcc", "plp"):
+    for snip, dc0, rawe, usee in itertools.product((0, 1), (0, 1), (0, 1), (0, 1)):
+        if kind == "spectrogram" and usee:
+            continue
+        extra = {} if kind == "spectrogram" else {"use_energy": usee}
+        _add(kind, 1900, 100 + snip * 8 + dc0 * 4 + rawe * 2 + usee, snip=snip, dc0=dc0, raw_energy=rawe, **extra)
+
+# windows x preemph
+for i, w in enumerate(WINDOWS):
+    _add("spectrogram", 1500, 200 + i, win=w, preemph=0.0)
+    _add("fbank", 1500, 210 + i, win=w)
+    _add("mfcc", 1500, 220 + i, win=w, preemph=0.5)
+_add("mfcc", 1500, 230, win="hanning")                           # prefix match: c/kaldi_mfcc.c:123
+
+# ragged / edge lengths: exactly one frame, one sample more, step boundaries
+for N in (400, 401, 559, 560, 561, 720, 3999):
+    _add("mfcc", N, 300 + N % 97, snip=1)
+    _add("fbank", N, 300 + N % 97, snip=0, B=40)
+for N in (80, 81, 100, 239, 240, 399):                         # shorter than a frame: only without snip_edges (heavy reflection)
+    _add("spectrogram", N, 400 + N, snip=0)
+    _add("mfcc", N, 400 + N, snip=0)
+
+# (B, C, Q) and fbank switches
+_add("mfcc", 2000, 500, B=23, C=13, Q=0.0)
+_add("mfcc", 2000, 501, B=23, C=23, Q=22.0)
+_add("mfcc", 2000, 502, B=23, C=2)
+_add("mfcc", 2000, 503, B=5, C=1)
+_add("fbank", 2000, 510, amp=1, lg=1)
+_add("fbank", 2000, 511, amp=0, lg=0)
+_add("fbank", 2000, 512, amp=1, lg=0, use_energy=1)
+_add("fbank", 2000, 513, B=1)
+_add("fbank", 2000, 514, B=1, use_energy=1)
+_add("fbank", 2000, 515, B=2, lof=0.0, hif=8000.0)
+_add("fbank", 2000, 516, B=23, lof=0.0, hif=9000.0)              # hif above Nyquist is not rejected: c/kaldi_mfcc.c:61
+_add("plp", 2000, 520, compress=1.0)
+_add("plp", 2000, 521, compress=0.5, Q=0.0, cep_scale=2.0)
+_add("plp", 2000, 522, B=15, C=8)
+_add("plp", 2000, 523, B=23, C=13, order=16)
+
+# other sample rates / FFT sizes
+_add("mfcc", 3000, 600, sr=8000.0, hif=4000.0, B=15)             # nfft 256
+_add("fbank", 3000, 601, sr=8000.0, hif=3800.0, B=23, snip=0)
+_add("spectrogram", 6000, 602, sr=22050.0)                       # L=551 -> nfft 1024 (sizes truncate in float)
+_add("mfcc", 12000, 603, sr=44100.0, hif=20000.0, B=40, C=20)    # L=1102 -> nfft 2048
+_add("fbank", 9000, 604, sr=32000.0, hif=16000.0, B=64, snip=0)  # L=800 -> nfft 1024
+_add("mfcc", 3000, 605, sr=16000.0, fl=10.0, fs=5.0)             # L=160 -> nfft 256
+_add("spectrogram", 3000, 606, sr=16000.0, fl=32.0, fs=16.0)     # L=512 == nfft
+_add("fbank", 30000, 607, sr=48000.0, fl=100.0, fs=40.0, hif=24000.0, B=80)   # L=4800 -> nfft 8192 (generic kernel)
+_add("mfcc", 900, 608, sr=16000.0, fl=1.0, fs=0.5, B=6, C=4, hif=8000.0)      # L=16 -> nfft 16 (generic kernel)
+
+# mean normalisation (intended D-wide form; reference-pinned only where D == B)
+_add("fbank", 2500, 700, mn0=1)
+_add("mfcc", 2500, 701, B=40, C=40, mn0=1)
+_add("mfcc", 2500, 702, mn0=1)
+_add("spectrogram", 2500, 703, mn0=1)
+_add("fbank", 2500, 704, use_energy=1, mn0=1)
+
+
+def case_id(c):
+    kind, N, seed, o = c
+    return "%s-N%d-%s" % (kind, N, "-".join("%s=%s" % kv for kv in sorted(o.items())) or "default")

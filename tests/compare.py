@@ -1,0 +1,48 @@
+"""Error measures shared by the CPU and GPU tests.
+
+Tolerances come from BASELINE.json's north star: max abs error <= 1e-4 on log-mel and cepstral features,
+<= 1e-5 relative on the power spectrum.  The reference only ever emits LOG power (c/kaldi_spectrogram.c:251), so
+the spectrogram criterion is |dlog| on bins within 1e-6 of the frame peak (a relative power error eps is a log error
+eps); bins below that are cancellation noise in any float32 FFT."""
+import numpy as np
+
+
+def max_err(kind, o, y, ref):
+    """Scalar error of y against ref in the unit the tolerance is stated in."""
+    y = np.asarray(y, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    if not np.isfinite(y).all():
+        return np.inf
+    if kind == "spectrogram":
+        if o.get("mn0", 0):
+            return np.abs(y - ref).max()
+        strong = ref > (ref.max(axis=1, keepdims=True) - np.log(1e6))
+        strong[:, 0] = True
+        return np.abs(y - ref)[strong].max()
+    if kind == "fbank" and not o.get("lg", 1):
+        # linear mel energies: relative to the frame's largest bin (first column may be a LOG energy: compare it in abs)
+        if o.get("use_energy", 0):
+            e0 = np.abs(y[:, 0] - ref[:, 0]).max()
+            y, ref = y[:, 1:], ref[:, 1:]
+        else:
+            e0 = 0.0
+        if o.get("mn0", 0):
+            scale = np.abs(ref).max() + 1e-30
+        else:
+            scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-30
+        return max(e0, (np.abs(y - ref) / scale).max())
+    return np.abs(y - ref).max()
+
+
+def check_parity(kind, o, got, oracle, truth=None, tol=1e-4, margin=2.0):
+    """The acceptance rule of SURVEY.md 7.3-1: HIP-vs-oracle <= tol, OR (where the float32 oracle itself is further
+    than tol from a float64 statement of the same algorithm, i.e. the case is ill-conditioned in float32)
+    HIP-vs-truth <= margin * oracle-vs-truth.  Returns (ok, e_go, e_gt, e_ot)."""
+    e_go = max_err(kind, o, got, oracle)
+    if truth is None:
+        return e_go <= tol, e_go, None, None
+    e_gt = max_err(kind, o, got, truth)
+    e_ot = max_err(kind, o, oracle, truth)
+    ok = (e_go <= tol) or (e_gt <= max(tol, margin * e_ot))
+    return ok, e_go, e_gt, e_ot

@@ -1,0 +1,207 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Acceptance rule and tolerances: tests/compare.py (north star: max abs error
+<= 1e-4 on log-mel / cepstra, <= 1e-5 relative on the power spectrum of the bins that carry the frame's energy)."""
+import numpy as np
+import pytest
+
+import np_truth as T
+import oracle_lib as O
+import signals
+from cases import GRID, case_id
+from compare import check_parity, max_err
+from speech_amd import api
+
+pytestmark = pytest.mark.gpu
+
+LEGACY = {"spectrogram": api.kaldi_spectrogram, "fbank": api.kaldi_fbank, "mfcc": api.kaldi_mfcc, "plp": api.kaldi_plp}
+TRUTH = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}
+ALIAS = {"fl": "frame_length", "fs": "frame_shift", "snip": "snip_edges", "win": "win_type"}
+
+
+def _legacy_kwargs(o):
+    return {ALIAS.get(k, k): v for k, v in o.items() if k != "order"}
+
+
+def _truth(kind, x, single, o):
+    o = dict(o)
+    mn0 = o.pop("mn0", 0)
+    y = TRUTH[kind](np.asarray(x, dtype=np.float64), single=single, **o)
+    return T.mean_norm(y) if mn0 else y
+
+
+def _tol(kind, o, single):
+    if not single:
+        return 1e-9
+    if kind == "spectrogram" and not o.get("mn0", 0):
+        return 1e-5 * 3     # |dlog P| on strong bins; 1e-5 relative plus the float32 front end's own rounding
+    return 1e-4
+
+
+@pytest.mark.parametrize("case", [c for c in GRID if "order" not in c[3]], ids=case_id)
+def test_dropin_single_precision_vs_oracle(case):
+    """kaldi_*_s through the drop-in symbols (host pointers), vs oracle_kaldi_*_s"""
+    kind, N, seed, o = case
+    x = signals.utterance(N, seed, sr=o.get("sr", 16000.0), dtype=np.float32)
+    rc, ref = O.run(kind, x, single=True, **o)
+    assert rc == 0
+    got = LEGACY[kind](x, **_legacy_kwargs(o))
+    ok, e_go, e_gt, e_ot = check_parity(kind, o, got, ref, _truth(kind, x, True, o), tol=_tol(kind, o, True))
+    assert ok, "hip-vs-oracle %.3g, hip-vs-f64 %.3g, oracle-vs-f64 %.3g" % (e_go, e_gt, e_ot)
+
+
+@pytest.mark.parametrize("case", [c for c in GRID if "order" not in c[3]][::3], ids=case_id)
+def test_dropin_double_precision_vs_oracle(case):
+    """kaldi_*_d vs oracle_kaldi_*_d: both float64, agreement to rounding"""
+    kind, N, seed, o = case
+    x = signals.utterance(N, seed, sr=o.get("sr", 16000.0), dtype=np.float64)
+    rc, ref = O.run(kind, x, single=False, **o)
+    assert rc == 0
+    got = LEGACY[kind](x, **_legacy_kwargs(o))
+    scale = max(1.0, float(np.abs(ref).max())) if (kind == "fbank" and not o.get("lg", 1)) else 1.0
+    assert max_err(kind, o, got, ref) <= 1e-9 * scale
+
+
+def test_quirks_on_device():
+    x = signals.utterance(3000, 5)
+    for kind in LEGACY:
+        y = LEGACY[kind](x)
+        assert np.array_equal(y[:, -1], y[:, -2]), kind
+
+
+def test_w_zero_and_errors_on_device(capfd):
+    import ctypes as C
+    from speech_amd import _lib
+    lib = _lib.load()
+    pf = C.POINTER(C.c_float)
+    x = np.ones(50, dtype=np.float32)
+    y = np.full(13, 7.0, dtype=np.float32)
+    assert lib.kaldi_mfcc_s(y.ctypes.data_as(pf), x.ctypes.data_as(pf), 50, 16000.0, 25.0, 10.0, 0, 0.0, 1, 1, 0.97, b"povey",
+                            20.0, 8000.0, 23, 13, 22.0, 0, 0) == 0
+    assert (y == 7.0).all()
+    with pytest.raises(api.SpeechError):
+        api.kaldi_mfcc(np.zeros(2000, dtype=np.float32), win_type="kaiser")
+    assert "window type must be rectangular, blackman, hamming, hann or povey" in capfd.readouterr().err
+
+
+def test_fbank_default_entry_points():
+    import ctypes as C
+    from speech_amd import _lib
+    lib = _lib.load()
+    x = signals.utterance(4000, 8)
+    W = api.frame_sizes(4000)[0]
+    y = np.zeros((W, 80), dtype=np.float32)
+    pf = C.POINTER(C.c_float)
+    rc = lib.kaldi_fbank_default_s(y.ctypes.data_as(pf), x.ctypes.data_as(pf), 4000, 10.0, 1, 0.0, 1, 1, 0.97, b"povey", 0, 20.0, 8000.0, 1, 0, 0)
+    assert rc == 0
+    _, ref = O.run("fbank", x, B=80)
+    assert max_err("fbank", {}, y, ref) <= 1e-4
+
+
+def test_plp_explicit_order_via_plan():
+    import torch
+    x = signals.utterance(4000, 9)
+    plan = api.Plan("plp", order=16, B=23, C=13)
+    b = api.Batch(plan, [4000])
+    X = torch.from_numpy(x).cuda()
+    Y = torch.zeros(b.total_out, device="cuda")
+    b.run(X, Y)
+    torch.cuda.synchronize()
+    got = Y.cpu().numpy().reshape(-1, 13)
+    _, ref = O.run("plp", x, order=16)
+    ok, e_go, e_gt, e_ot = check_parity("plp", {}, got, ref, T.plp(x.astype(np.float64), order=16))
+    assert ok, (e_go, e_gt, e_ot)
+
+
+@pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {}),
+                                    ("mfcc", dict(snip=0)), ("fbank", dict(B=80, snip=0, use_energy=1))])
+def test_ragged_batch_equals_per_utterance(kind, o):
+    """one launch over a ragged batch == the per-utterance calls, bit for bit"""
+    import torch
+    lens = [16000, 400, 401, 4799, 32000, 559, 560, 12345, 48000, 7777]
+    if o.get("snip", 1) == 0:
+        lens += [80, 100, 239]
+    xs = [signals.utterance(n, 900 + i) for i, n in enumerate(lens)]
+    plan = api.Plan(kind, **o)
+    b = api.Batch(plan, lens)
+    X = torch.from_numpy(np.concatenate(xs)).cuda()
+    Y = torch.full((b.total_out,), float("nan"), device="cuda")
+    b.run(X, Y, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    Yh = Y.cpu().numpy()
+    assert np.isfinite(Yh).all()
+    for i, x in enumerate(xs):
+        W = int(b.n_frames[i])
+        got = Yh[int(b.y_off[i]):int(b.y_off[i]) + W * plan.D].reshape(W, plan.D)
+        single = LEGACY[kind](x, **_legacy_kwargs(o))
+        assert np.array_equal(got, single), (kind, i, lens[i])
+        _, ref = O.run(kind, x, **o)
+        ok, e_go, e_gt, e_ot = check_parity(kind, o, got, ref, _truth(kind, x, True, o), tol=_tol(kind, o, True))
+        assert ok, (kind, i, e_go, e_gt, e_ot)
+
+
+def test_tuned_and_generic_kernels_agree():
+    """where a tuned gfx950 kernel exists, it and the generic kernel are two independent HIP implementations"""
+    import torch
+    x = signals.utterance(24000, 77)
+    X = torch.from_numpy(x).cuda()
+    for kind, o in [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", {}), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {})]:
+        outs = []
+        for fg in (0, 1):
+            plan = api.Plan(kind, force_generic=fg, **o)
+            b = api.Batch(plan, [x.size])
+            Y = torch.zeros(b.total_out, device="cuda")
+            b.run(X, Y)
+            torch.cuda.synchronize()
+            outs.append(Y.cpu().numpy().reshape(-1, plan.D))
+        assert max_err(kind, o, outs[0], outs[1]) <= 2e-4, kind
+
+
+def test_full_size_config1_and_properties():
+    """BASELINE config 1 at full size (one 10 s utterance, 998 x 13) vs the oracle, plus size-independent properties."""
+    x = signals.utterance(160000, 1234)
+    got = api.kaldi_mfcc(x)
+    assert got.shape == (998, 13)
+    _, ref = O.run("mfcc", x)
+    ok, e_go, e_gt, e_ot = check_parity("mfcc", {}, got, ref, T.mfcc(x.astype(np.float64)))
+    assert ok, (e_go, e_gt, e_ot)
+    # time-shift property with snip_edges: dropping the first `stp` samples drops exactly the first frame
+    got2 = api.kaldi_mfcc(x[160:])
+    assert np.array_equal(got2, got[1:])
+    # scaling property: log-mel shifts by 2 log a, so c0 shifts by sqrt(B) * 2 log a * ... and c1.. are unchanged (dither=0)
+    got3 = api.kaldi_mfcc(x * np.float32(0.5))
+    assert np.abs(got3[:, 1:] - got[:, 1:]).max() < 2e-4
+
+
+def test_large_batch_config2_properties():
+    """BASELINE config 2 at reduced count (64 x 10 s) on device: every utterance of a batch of identical audio gives
+    identical features, and they match the oracle for the first."""
+    import torch
+    x = signals.utterance(160000, 4321)
+    n = 64
+    plan = api.Plan("spectrogram")
+    b = api.Batch(plan, [160000] * n)
+    X = torch.from_numpy(x).cuda().repeat(n)
+    Y = torch.zeros(b.total_out, device="cuda")
+    b.run(X, Y)
+    torch.cuda.synchronize()
+    Yv = Y.view(n, 998, 257)
+    assert bool((Yv == Yv[0:1]).all())
+    _, ref = O.run("spectrogram", x)
+    ok, e_go, e_gt, e_ot = check_parity("spectrogram", {}, Yv[0].cpu().numpy(), ref, T.spectrogram(x.astype(np.float64)), tol=3e-5)
+    assert ok, (e_go, e_gt, e_ot)
+
+
+def test_dither_is_seeded_and_has_the_right_scale():
+    import torch
+    x = np.zeros(16000, dtype=np.float32)
+    outs = []
+    for seed in (1, 1, 2):
+        plan = api.Plan("spectrogram", dither=1.0, dither_seed=seed, dc0=0, preemph=0.0, win="rectangular", raw_energy=1)
+        b = api.Batch(plan, [16000])
+        Y = torch.zeros(b.total_out, device="cuda")
+        b.run(torch.from_numpy(x).cuda(), Y)
+        torch.cuda.synchronize()
+        outs.append(Y.cpu().numpy().reshape(-1, 257))
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
+    # bin 0 is log of the frame energy of pure unit-variance noise: E = 400 on average
+    assert abs(np.exp(outs[0][:, 0]).mean() - 400.0) < 20.0
