@@ -47,6 +47,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64.so.7; if torch is importable,
+    # load it first so that libspeech.so (DT_NEEDED libamdhip64.so.7) binds to the same copy instead of /opt/rocm's.
+    # Two initialised copies fail with "No HIP GPUs are available" in whichever comes second.
+    if not os.environ.get("SPEECH_AMD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise OSError("libspeech.so not found at %s: build it with `make -C speech_amd/csrc` "
                       "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
