@@ -1,21 +1,352 @@
-// fast_kernels.hip -- tuned gfx950 fp32 kernels (placeholder: nothing tuned yet, every plan uses generic_kernels.hip).
+// fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, dither off).
+//
+// Unit of work: a QUAD = 4 consecutive frames of one utterance, owned by ONE 64-lane wavefront
+// (16 lanes per frame).  A 256-thread workgroup takes a tile of 16 consecutive frames, one quad per wave.
+//
+//   audio      the wave loads the quad's contiguous sample span ((4-1)*stp + L floats) with coalesced
+//              global loads into its private LDS slice; the overlapping frames are cut from LDS
+//              (reference: gather, c/kaldi_mfcc.c:216-240).
+//   front end  DC removal, raw energy, pre-emphasis, window in registers; the two sums are DPP
+//              reductions over the frame's 16 lanes (reference: c/kaldi_mfcc.c:265-301).
+//   FFT        512-point real FFT as a 256-point complex FFT of z[n] = x[2n] + i x[2n+1], n = n1 + 16 n2:
+//              lane n1 does a 16-point FFT over n2 in registers, multiplies by W256^(n1 k2), the frame's
+//              16x16 block is transposed through the wave's LDS slice, lane k2 does the second 16-point
+//              FFT over n1.  One LDS round trip per frame, no workgroup barrier (replaces FFTW R2HC,
+//              c/kaldi_mfcc.c:304).
+//   untangle   lanes k2 and 16-k2 swap half of their outputs (ds_bpermute) and each computes the power of
+//              bins k and 256-k for 8 values of k (reference: power, c/kaldi_mfcc.c:307-310).
+//   epilogue   spectrogram: log / energy / Nyquist quirk (c/kaldi_spectrogram.c:236-251), staged in LDS so
+//              the quad's 4 x 257 outputs leave as one contiguous coalesced run.
 #include "speech_internal.hpp"
+#include <cfloat>
+#include <cmath>
 
 namespace speech {
 
-struct FastTables { int unused; };
+struct FastTables {
+    float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[9][16] complex
+};
+void fast_tables_destroy(FastTables *t);
 
-bool fast_supported(const speech_opts &, size_t, size_t) { return false; }
-int fast_tile_frames(const speech_opts &) { return GENERIC_TILE_FRAMES; }
-FastTables *fast_tables_create(const speech_opts &, size_t, size_t, size_t, size_t, size_t, size_t, const std::vector<float> &,
+namespace {
+
+constexpr int NT = 256;                 // threads per workgroup (4 waves)
+constexpr int QF = 4;                   // frames per wave (quad)
+constexpr int TILE = 16;                // frames per workgroup
+constexpr int NFFT = 512, NC = 256, FB = 257;
+constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 9 * 16 * 2;
+constexpr int TR_PITCH = 18;            // complex elements per transposition row (16 + 2 pad: 16-B aligned rows, conflict-free)
+constexpr int TR_FLOATS = QF * 16 * TR_PITCH * 2;
+
+struct FastParams {
+    const float *X;
+    float *Y;
+    const UttDesc *utts;
+    const TileDesc *tiles;
+    uint32_t ntiles;
+    int L, stp, D, span;                // span: floats of the wave's audio slice (multiple of 4)
+    int snip_edges, dc0, want_pre, want_post;
+    float preemph;                      // 0 when pre-emphasis is off
+    const float *tab;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over the 16 lanes of a DPP row; every lane of the row ends with the same bits
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);              // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);              // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);             // row_half_mirror
+    v += dpp_mov<0x140>(v);             // row_mirror
+    return v;
+}
+
+// LDS traffic between the lanes of ONE wave needs no s_barrier (a wave's DS operations execute in order);
+// this only stops the compiler from moving LDS accesses across the hand-over point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// forward 4-point DFT in place: (a,b,c,d) = x0..x3 -> X0..X3
+__device__ __forceinline__ void fft4(float &ar, float &ai, float &br, float &bi, float &cr, float &ci, float &dr, float &di)
+{
+    const float t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+    const float t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
+    ar = t0r + t2r; ai = t0i + t2i;
+    cr = t0r - t2r; ci = t0i - t2i;
+    br = t1r + t3i; bi = t1i - t3r;
+    dr = t1r - t3i; di = t1i + t3r;
+}
+
+__device__ __forceinline__ void cmul(float &r, float &i, const float wr, const float wi)
+{
+    const float tr = r * wr - i * wi;
+    i = r * wi + i * wr;
+    r = tr;
+}
+
+// position of output X[k] after fft16()
+__host__ __device__ constexpr int P16(int k) { return (k >> 2) + 4 * (k & 3); }
+
+// forward 16-point DFT on registers, input natural order, output X[k] at position P16(k)
+__device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16])
+{
+    constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, H = 0.70710678118654752440f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { fft4(re[a], im[a], re[a + 4], im[a + 4], re[a + 8], im[a + 8], re[a + 12], im[a + 12]); }
+    // position a + 4 kb  *=  W16^(a kb)
+    cmul(re[1 + 4], im[1 + 4], C1, -S1);                 // W^1
+    cmul(re[1 + 8], im[1 + 8], H, -H);                   // W^2
+    cmul(re[1 + 12], im[1 + 12], S1, -C1);               // W^3
+    cmul(re[2 + 4], im[2 + 4], H, -H);                   // W^2
+    { const float t = re[2 + 8]; re[2 + 8] = im[2 + 8]; im[2 + 8] = -t; }       // W^4 = -i
+    cmul(re[2 + 12], im[2 + 12], -H, -H);                // W^6
+    cmul(re[3 + 4], im[3 + 4], S1, -C1);                 // W^3
+    cmul(re[3 + 8], im[3 + 8], -H, -H);                  // W^6
+    cmul(re[3 + 12], im[3 + 12], -C1, S1);               // W^9
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { fft4(re[4 * b], im[4 * b], re[4 * b + 1], im[4 * b + 1], re[4 * b + 2], im[4 * b + 2], re[4 * b + 3], im[4 * b + 3]); }
+}
+
+__device__ __forceinline__ float floor_log(float v)
+{
+    return __log2f(fmaxf(v, FLT_EPSILON)) * 0.69314718055994530942f;
+}
+
+// Load the wave's audio slice: `need` samples starting at utterance-relative position s0 (may be negative or run past N
+// when snip_edges is off: reflected as c/kaldi_mfcc.c:228).
+__device__ __forceinline__ void load_span(float *s_aud, const float *xu, long long s0, int need, long long N, int lane)
+{
+    if (s0 >= 0 && s0 + need <= N)
+    {
+        const float *src = xu + s0;
+        for (int i = lane; i < need; i += 64) { s_aud[i] = src[i]; }
+    }
+    else
+    {
+        for (int i = lane; i < need; i += 64)
+        {
+            long long n = s0 + i;
+            while (n < 0 || n >= N) { n = (n < 0) ? -n - 1 : 2 * N - 1 - n; }
+            s_aud[i] = xu[n];
+        }
+    }
+}
+
+// One frame per 16-lane row: front end + 512-point real FFT + power.
+// On return lane k2 (= lane & 15) holds, for k1 = 0..7 (and k1 = 8, meaningful in lane k2 == 0 only):
+//   pa[k1] = |X[k]|^2, pb[k1] = |X[256 - k]|^2 with k = k2 + 16 k1;   rawe = the frame's (floored) energy.
+__device__ __forceinline__ void frame_power(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
+                                            float (&pa)[9], float (&pb)[9], float &rawe)
+{
+    const int f = lane >> 4, n1 = lane & 15;
+    const int L = p.L;
+    float re[16], im[16];
+    float sum = 0.0f;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2)
+    {
+        const int l = 2 * n1 + 32 * n2;
+        re[n2] = (l < L) ? fa[l] : 0.0f;
+        im[n2] = (l + 1 < L) ? fa[l + 1] : 0.0f;
+        sum += re[n2] + im[n2];
+    }
+    float mean = 0.0f;
+    if (p.dc0) { mean = row16_sum(sum) / (float)L; }                        // c/kaldi_mfcc.c:265-271
+    const float pre = p.preemph;
+    const float *win = s_tab + TAB_WIN;
+    float e = 0.0f;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2)
+    {
+        const int l = 2 * n1 + 32 * n2;
+        const float de = (l < L) ? re[n2] - mean : 0.0f;
+        const float dq = (l + 1 < L) ? im[n2] - mean : 0.0f;
+        if (p.want_pre) { e += de * de; e += dq * dq; }                     // c/kaldi_mfcc.c:274-279
+        // pre-emphasis: y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0]         c/kaldi_mfcc.c:282-288
+        const float dprev = (l > 0) ? ((l - 1 < L) ? fa[(l > 0) ? l - 1 : 0] - mean : 0.0f) : de;
+        float ye = de - pre * dprev;
+        float yo = dq - pre * de;
+        ye *= win[l]; yo *= win[l + 1];                                     // c/kaldi_mfcc.c:291 (table is zero beyond L)
+        if (p.want_post) { e += ye * ye; e += yo * yo; }                    // c/kaldi_mfcc.c:295-301
+        re[n2] = ye; im[n2] = yo;
+    }
+    rawe = fmaxf(row16_sum(e), FLT_EPSILON);
+
+    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS
+    fft16(re, im);
+    float *trf = s_tr + f * (16 * TR_PITCH * 2);
+    const float2 *tw1 = reinterpret_cast<const float2 *>(s_tab + TAB_TW1);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2)
+    {
+        float ar = re[P16(k2)], ai = im[P16(k2)];
+        if (k2 > 0) { const float2 w = tw1[k2 * 16 + n1]; cmul(ar, ai, w.x, w.y); }
+        *reinterpret_cast<float2 *>(trf + (k2 * TR_PITCH + n1) * 2) = make_float2(ar, ai);
+    }
+    wave_sync();
+    const int k2 = n1;                                                      // the lane's role after the transpose
+#pragma unroll
+    for (int n = 0; n < 16; n += 2)
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(trf + (k2 * TR_PITCH + n) * 2);
+        re[n] = v.x; im[n] = v.y; re[n + 1] = v.z; im[n + 1] = v.w;
+    }
+    wave_sync();
+    fft16(re, im);                                                          // Z[k2 + 16 k1] at position P16(k1)
+
+    // untangle: partner lane (16 - k2) mod 16 of the same row offers Z[256 - k]
+    const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
+    const bool lane0 = (k2 == 0);
+    const float2 *tw2 = reinterpret_cast<const float2 *>(s_tab + TAB_TW2);
+#pragma unroll
+    for (int k1 = 0; k1 < 9; ++k1)
+    {
+        const float offr = lane0 ? re[P16((16 - k1) & 15)] : re[P16((15 - k1) & 15)];
+        const float offi = lane0 ? im[P16((16 - k1) & 15)] : im[P16((15 - k1) & 15)];
+        const float zpr = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(offr)));
+        const float zpi = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(offi)));
+        const float zkr = re[P16(k1)], zki = im[P16(k1)];
+        const float er = zkr + zpr, ei = zki - zpi;                         // 2E = Z[k] + conj Z[256-k]
+        float tr = zki + zpi, ti = zpr - zkr;                               // 2O = -i (Z[k] - conj Z[256-k])
+        const float2 w = tw2[k1 * 16 + k2];                                 // exp(-i pi k / 256)
+        cmul(tr, ti, w.x, w.y);
+        const float ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
+        pa[k1] = 0.25f * (ar * ar + ai * ai);
+        pb[k1] = 0.25f * (br * br + bi * bi);
+    }
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one contiguous run of
+// tiles (neighbouring tiles share 240 of their 2800 samples: the overlap then hits in that XCD's L2).
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t ntiles)
+{
+    const uint32_t x = b & 7u, i = b >> 3, q = ntiles >> 3, r = ntiles & 7u;
+    return x * q + (x < r ? x : r) + i;
+}
+
+__global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float *s_tab = smem;
+    float *s_aud = smem + TAB_FLOATS + wv * (p.span + TR_FLOATS);
+    float *s_tr = s_aud + p.span;
+    for (int i = tid; i < TAB_FLOATS; i += NT) { s_tab[i] = p.tab[i]; }
+
+    const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
+    const UttDesc utt = p.utts[tile.utt];
+    const int fq = wv * QF;                                                 // first frame of this wave's quad within the tile
+    const int nfr = min((int)tile.nframes - fq, QF);
+    if (nfr > 0)
+    {
+        const long long w0 = (long long)tile.frame0 + fq;
+        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
+        load_span(s_aud, p.X + utt.x_off, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
+    }
+    __syncthreads();                                                        // tables (and, wave-locally, the span) are in LDS
+    if (nfr <= 0) { return; }
+
+    const int f = lane >> 4, k2 = lane & 15;
+    float pa[9], pb[9], rawe;
+    frame_power(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
+
+    // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything
+    float *so = s_tr + f * FB;                                              // output staging aliases the transposition slice
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+    {
+        const int k = k2 + 16 * k1;
+        so[k] = floor_log((k == 0) ? rawe : pa[k1]);
+        if (k > 0)
+        {
+            const float lb = floor_log(pb[k1]);
+            so[NC - k] = lb;
+            if (k == 1) { so[NC] = lb; }
+        }
+    }
+    if (k2 == 0) { so[128] = floor_log(pa[8]); }
+    wave_sync();
+    float *y = p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB;
+    const int nout = nfr * FB;
+    for (int i = lane; i < nout; i += 64) { y[i] = s_tr[i]; }
+}
+
+}  // namespace
+
+bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
+{
+    if (o.dtype != SPEECH_F32 || nfft != (size_t)NFFT) { return false; }
+    if ((float)o.dither > FLT_EPSILON) { return false; }                    // dither runs on the generic kernel
+    const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
+    if (stp < 1u || stp > 1024u || L > (size_t)NFFT) { return false; }
+    return o.kind == SPEECH_SPECTROGRAM;
+}
+
+int fast_tile_frames(const speech_opts &) { return TILE; }
+
+FastTables *fast_tables_create(const speech_opts &, size_t L, size_t, size_t, size_t, size_t, size_t, const std::vector<float> &win,
                                const std::vector<float> &, const std::vector<int> &, const std::vector<int> &, const std::vector<float> &,
                                const std::vector<float> &, const std::vector<float> &, const std::vector<float> &, std::string *err)
 {
-    if (err) { *err = "no tuned kernel"; }
-    return nullptr;
+    std::vector<float> tab(TAB_FLOATS, 0.0f);
+    for (size_t l = 0; l < L && l < (size_t)NFFT; ++l) { tab[TAB_WIN + l] = win[l]; }
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (int k2 = 0; k2 < 16; ++k2) { for (int n1 = 0; n1 < 16; ++n1) {
+        const long double a = -2.0L * pi * (long double)(n1 * k2) / (long double)NC;
+        tab[TAB_TW1 + (k2 * 16 + n1) * 2] = (float)cosl(a); tab[TAB_TW1 + (k2 * 16 + n1) * 2 + 1] = (float)sinl(a); } }
+    for (int k1 = 0; k1 < 9; ++k1) { for (int k2 = 0; k2 < 16; ++k2) {
+        const long double a = -pi * (long double)(k2 + 16 * k1) / (long double)NC;
+        tab[TAB_TW2 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[TAB_TW2 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
+    FastTables *t = new (std::nothrow) FastTables();
+    if (!t) { if (err) { *err = "out of host memory"; } return nullptr; }
+    t->d_tab = nullptr;
+    hipError_t e = hipMalloc((void **)&t->d_tab, tab.size() * sizeof(float));
+    if (e == hipSuccess) { e = hipMemcpy(t->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); }
+    if (e != hipSuccess) { if (err) { *err = hipGetErrorString(e); } fast_tables_destroy(t); return nullptr; }
+    return t;
 }
-void fast_tables_destroy(FastTables *t) { delete t; }
+
+void fast_tables_destroy(FastTables *t)
+{
+    if (!t) { return; }
+    if (t->d_tab) { (void)hipFree(t->d_tab); }
+    delete t;
+}
+
 size_t fast_scratch_elems(const FastTables *, size_t) { return 0; }
-hipError_t launch_fast(const FastTables *, const FrameParams<float> &, float *, hipStream_t, hipEvent_t, hipEvent_t) { return hipErrorNotSupported; }
+
+hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float *, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    if (fp.ntiles == 0) { return hipSuccess; }
+    FastParams p;
+    p.X = fp.X; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
+    p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
+    p.span = ((QF - 1) * fp.stp + NFFT + 3) & ~3;
+    p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
+    p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
+    p.tab = t->d_tab;
+    const size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * (p.span + TR_FLOATS)) * sizeof(float);
+    hipError_t e = hipSuccess;
+    if (lds > 48 * 1024)
+    {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fast_spectrogram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { return e; }
+    }
+    if (ev0) { e = hipEventRecord(ev0, s); if (e != hipSuccess) { return e; } }
+    hipLaunchKernelGGL(fast_spectrogram_kernel, dim3(fp.ntiles), dim3(NT), lds, s, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) { return e; }
+    if (ev1) { e = hipEventRecord(ev1, s); }
+    return e;
+}
 
 }  // namespace speech
