@@ -1,4 +1,5 @@
-// fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, dither off).
+// fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, even frame shift,
+// dither off).  Everything else runs on generic_kernels.hip.
 //
 // Unit of work: a QUAD = 4 consecutive frames of one utterance, owned by ONE 64-lane wavefront
 // (16 lanes per frame).  A 256-thread workgroup takes a tile of 16 consecutive frames, one quad per wave.
@@ -10,13 +11,17 @@
 //              reductions over the frame's 16 lanes (reference: c/kaldi_mfcc.c:265-301).
 //   FFT        512-point real FFT as a 256-point complex FFT of z[n] = x[2n] + i x[2n+1], n = n1 + 16 n2:
 //              lane n1 does a 16-point FFT over n2 in registers, multiplies by W256^(n1 k2), the frame's
-//              16x16 block is transposed through the wave's LDS slice, lane k2 does the second 16-point
-//              FFT over n1.  One LDS round trip per frame, no workgroup barrier (replaces FFTW R2HC,
-//              c/kaldi_mfcc.c:304).
+//              16x16 block is transposed through the wave's LDS slice (real parts, then imaginary parts,
+//              XOR-swizzled so that the b32 writes and b128 reads are conflict-free), lane k2 does the second
+//              16-point FFT over n1.  No workgroup barrier (replaces FFTW R2HC, c/kaldi_mfcc.c:304).
 //   untangle   lanes k2 and 16-k2 swap half of their outputs (ds_bpermute) and each computes the power of
 //              bins k and 256-k for 8 values of k (reference: power, c/kaldi_mfcc.c:307-310).
 //   epilogue   spectrogram: log / energy / Nyquist quirk (c/kaldi_spectrogram.c:236-251), staged in LDS so
 //              the quad's 4 x 257 outputs leave as one contiguous coalesced run.
+//              fbank / mfcc / plp: the tile's 16 x 257 power block is staged in LDS and contracted with the
+//              banded mel matrix on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32 fma chains); MFCC
+//              adds a second MFMA contraction with the lifter-scaled DCT matrix; PLP an MFMA with the IDFT
+//              bases followed by one lane per frame running Levinson-Durbin and the cepstral recursion.
 #include "speech_internal.hpp"
 #include <cfloat>
 #include <cmath>
@@ -25,6 +30,8 @@ namespace speech {
 
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[9][16] complex
+    int nz;            // ceil(L / 32): rows of 32 samples that hold data
+    bool attr_set;
 };
 void fast_tables_destroy(FastTables *t);
 
@@ -35,8 +42,8 @@ constexpr int QF = 4;                   // frames per wave (quad)
 constexpr int TILE = 16;                // frames per workgroup
 constexpr int NFFT = 512, NC = 256, FB = 257;
 constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 9 * 16 * 2;
-constexpr int TR_PITCH = 18;            // complex elements per transposition row (16 + 2 pad: 16-B aligned rows, conflict-free)
-constexpr int TR_FLOATS = QF * 16 * TR_PITCH * 2;
+constexpr int TR_WAVE = 1032;           // floats of a wave's transposition slice: 4 frames x 256 (+8 so that 4 x 257 outputs fit)
+constexpr int PP = 258;                 // pitch of the 16 x 257 power tile that aliases the four slices (4 x 1032 = 16 x 258)
 
 struct FastParams {
     const float *X;
@@ -44,7 +51,7 @@ struct FastParams {
     const UttDesc *utts;
     const TileDesc *tiles;
     uint32_t ntiles;
-    int L, stp, D, span;                // span: floats of the wave's audio slice (multiple of 4)
+    int L, stp, D, span;                // span: floats of a wave's audio slice (multiple of 4)
     int snip_edges, dc0, want_pre, want_post;
     float preemph;                      // 0 when pre-emphasis is off
     const float *tab;
@@ -122,7 +129,7 @@ __device__ __forceinline__ float floor_log(float v)
 }
 
 // Load the wave's audio slice: `need` samples starting at utterance-relative position s0 (may be negative or run past N
-// when snip_edges is off: reflected as c/kaldi_mfcc.c:228).
+// when snip_edges is off: reflected as c/kaldi_mfcc.c:228).  All arguments but `lane` are wave-uniform.
 __device__ __forceinline__ void load_span(float *s_aud, const float *xu, long long s0, int need, long long N, int lane)
 {
     if (s0 >= 0 && s0 + need <= N)
@@ -141,79 +148,107 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, long lo
     }
 }
 
-// One frame per 16-lane row: front end + 512-point real FFT + power.
+// One frame per 16-lane row: front end + 512-point real FFT + power.  NZ = ceil(L / 32): rows n2 < NZ-1 are full,
+// row NZ-1 is cut at L, rows >= NZ are the zero padding (never read, folded at compile time).
+// `fa` (8-byte aligned) is the frame's first sample in the wave's audio slice, `s_tr` the wave's transposition slice.
 // On return lane k2 (= lane & 15) holds, for k1 = 0..7 (and k1 = 8, meaningful in lane k2 == 0 only):
 //   pa[k1] = |X[k]|^2, pb[k1] = |X[256 - k]|^2 with k = k2 + 16 k1;   rawe = the frame's (floored) energy.
+template <int NZ>
 __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
                                             float (&pa)[9], float (&pb)[9], float &rawe)
 {
     const int f = lane >> 4, n1 = lane & 15;
     const int L = p.L;
+    const int llast = 2 * n1 + 32 * (NZ - 1);
+    const bool ve = llast < L, vo = llast + 1 < L;                          // validity of the lane's two samples in row NZ-1
     float re[16], im[16];
     float sum = 0.0f;
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2)
     {
-        const int l = 2 * n1 + 32 * n2;
-        re[n2] = (l < L) ? fa[l] : 0.0f;
-        im[n2] = (l + 1 < L) ? fa[l + 1] : 0.0f;
-        sum += re[n2] + im[n2];
+        if (n2 < NZ)
+        {
+            const float2 v = *reinterpret_cast<const float2 *>(fa + 2 * n1 + 32 * n2);
+            re[n2] = (n2 < NZ - 1 || ve) ? v.x : 0.0f;
+            im[n2] = (n2 < NZ - 1 || vo) ? v.y : 0.0f;
+            sum += re[n2]; sum += im[n2];
+        }
+        else { re[n2] = 0.0f; im[n2] = 0.0f; }
     }
     float mean = 0.0f;
     if (p.dc0) { mean = row16_sum(sum) / (float)L; }                        // c/kaldi_mfcc.c:265-271
     const float pre = p.preemph;
-    const float *win = s_tab + TAB_WIN;
+    const float2 *win = reinterpret_cast<const float2 *>(s_tab + TAB_WIN);
+    const float *fprev = fa + ((n1 > 0) ? 2 * n1 - 1 : 0);                  // sample before the lane's even sample of row 0 (itself for l = 0)
     float e = 0.0f;
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2)
+    for (int n2 = 0; n2 < NZ; ++n2)
     {
-        const int l = 2 * n1 + 32 * n2;
-        const float de = (l < L) ? re[n2] - mean : 0.0f;
-        const float dq = (l + 1 < L) ? im[n2] - mean : 0.0f;
+        float de = re[n2] - mean, dq = im[n2] - mean;
+        if (n2 == NZ - 1) { de = ve ? de : 0.0f; dq = vo ? dq : 0.0f; }
         if (p.want_pre) { e += de * de; e += dq * dq; }                     // c/kaldi_mfcc.c:274-279
         // pre-emphasis: y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0]         c/kaldi_mfcc.c:282-288
-        const float dprev = (l > 0) ? ((l - 1 < L) ? fa[(l > 0) ? l - 1 : 0] - mean : 0.0f) : de;
-        float ye = de - pre * dprev;
-        float yo = dq - pre * de;
-        ye *= win[l]; yo *= win[l + 1];                                     // c/kaldi_mfcc.c:291 (table is zero beyond L)
+        const float xp = (n2 == 0) ? fprev[0] : fa[2 * n1 + 32 * n2 - 1];
+        const float2 w = win[n1 + 16 * n2];                                 // c/kaldi_mfcc.c:291 (table is zero beyond L)
+        float ye = (de - pre * (xp - mean)) * w.x;
+        float yo = (dq - pre * de) * w.y;
+        if (n2 == NZ - 1) { ye = ve ? ye : 0.0f; yo = vo ? yo : 0.0f; }     // the slice beyond the quad's last sample is not initialised
         if (p.want_post) { e += ye * ye; e += yo * yo; }                    // c/kaldi_mfcc.c:295-301
         re[n2] = ye; im[n2] = yo;
     }
     rawe = fmaxf(row16_sum(e), FLT_EPSILON);
 
-    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS
+    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS (swizzled: element (k2, n) of a frame
+    // lives at k2*16 + 4*((n>>2) ^ (k2>>2)) + (n&3))
     fft16(re, im);
-    float *trf = s_tr + f * (16 * TR_PITCH * 2);
     const float2 *tw1 = reinterpret_cast<const float2 *>(s_tab + TAB_TW1);
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2)
+    for (int k2 = 1; k2 < 16; ++k2)
     {
-        float ar = re[P16(k2)], ai = im[P16(k2)];
-        if (k2 > 0) { const float2 w = tw1[k2 * 16 + n1]; cmul(ar, ai, w.x, w.y); }
-        *reinterpret_cast<float2 *>(trf + (k2 * TR_PITCH + n1) * 2) = make_float2(ar, ai);
+        const float2 w = tw1[k2 * 16 + n1];
+        cmul(re[P16(k2)], im[P16(k2)], w.x, w.y);
+    }
+    float *trf = s_tr + f * 256;
+    int woff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
+    const int k2 = n1;                                                      // the lane's role after the transpose
+    const float *rrow = trf + k2 * 16;
+    const int rq = k2 >> 2;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = re[P16(kk)]; }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
+        re[4 * q] = v.x; re[4 * q + 1] = v.y; re[4 * q + 2] = v.z; re[4 * q + 3] = v.w;
     }
     wave_sync();
-    const int k2 = n1;                                                      // the lane's role after the transpose
 #pragma unroll
-    for (int n = 0; n < 16; n += 2)
+    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = im[P16(kk)]; }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
     {
-        const float4 v = *reinterpret_cast<const float4 *>(trf + (k2 * TR_PITCH + n) * 2);
-        re[n] = v.x; im[n] = v.y; re[n + 1] = v.z; im[n + 1] = v.w;
+        const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
+        im[4 * q] = v.x; im[4 * q + 1] = v.y; im[4 * q + 2] = v.z; im[4 * q + 3] = v.w;
     }
     wave_sync();
     fft16(re, im);                                                          // Z[k2 + 16 k1] at position P16(k1)
 
-    // untangle: partner lane (16 - k2) mod 16 of the same row offers Z[256 - k]
+    // untangle: partner lane (16 - k2) mod 16 of the same row holds Z[256 - k] in register 15 - k1; lane 0 is its own
+    // partner with register (16 - k1) mod 16
     const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
     const bool lane0 = (k2 == 0);
     const float2 *tw2 = reinterpret_cast<const float2 *>(s_tab + TAB_TW2);
 #pragma unroll
     for (int k1 = 0; k1 < 9; ++k1)
     {
-        const float offr = lane0 ? re[P16((16 - k1) & 15)] : re[P16((15 - k1) & 15)];
-        const float offi = lane0 ? im[P16((16 - k1) & 15)] : im[P16((15 - k1) & 15)];
-        const float zpr = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(offr)));
-        const float zpi = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(offi)));
+        float zpr = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(re[P16((15 - k1) & 15)])));
+        float zpi = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(im[P16((15 - k1) & 15)])));
+        zpr = lane0 ? re[P16((16 - k1) & 15)] : zpr;
+        zpi = lane0 ? im[P16((16 - k1) & 15)] : zpi;
         const float zkr = re[P16(k1)], zki = im[P16(k1)];
         const float er = zkr + zpr, ei = zki - zpi;                         // 2E = Z[k] + conj Z[256-k]
         float tr = zki + zpi, ti = zpr - zkr;                               // 2O = -i (Z[k] - conj Z[256-k])
@@ -226,20 +261,22 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one contiguous run of
-// tiles (neighbouring tiles share 240 of their 2800 samples: the overlap then hits in that XCD's L2).
+// tiles (neighbouring tiles share L - stp of their samples: the overlap then hits in that XCD's L2).
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t ntiles)
 {
     const uint32_t x = b & 7u, i = b >> 3, q = ntiles >> 3, r = ntiles & 7u;
     return x * q + (x < r ? x : r) + i;
 }
 
+template <int NZ>
 __global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
-    float *s_aud = smem + TAB_FLOATS + wv * (p.span + TR_FLOATS);
-    float *s_tr = s_aud + p.span;
+    float *s_aud = smem + TAB_FLOATS + wv * p.span;
+    float *s_tr = smem + TAB_FLOATS + (NT / 64) * p.span + wv * TR_WAVE;
     for (int i = tid; i < TAB_FLOATS; i += NT) { s_tab[i] = p.tab[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
@@ -257,27 +294,45 @@ __global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p
 
     const int f = lane >> 4, k2 = lane & 15;
     float pa[9], pb[9], rawe;
-    frame_power(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
+    frame_power<NZ>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
 
     // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything
     float *so = s_tr + f * FB;                                              // output staging aliases the transposition slice
-#pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1)
     {
-        const int k = k2 + 16 * k1;
-        so[k] = floor_log((k == 0) ? rawe : pa[k1]);
-        if (k > 0)
-        {
-            const float lb = floor_log(pb[k1]);
-            so[NC - k] = lb;
-            if (k == 1) { so[NC] = lb; }
-        }
+        const float la = floor_log((k2 == 0) ? rawe : pa[0]);
+        const float lb = floor_log(pb[0]);
+        so[k2] = la;
+        if (k2 > 0) { so[NC - k2] = lb; }
+        if (k2 == 1) { so[NC] = lb; }
+    }
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1)
+    {
+        so[k2 + 16 * k1] = floor_log(pa[k1]);
+        so[NC - 16 * k1 - k2] = floor_log(pb[k1]);
     }
     if (k2 == 0) { so[128] = floor_log(pa[8]); }
     wave_sync();
     float *y = p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB;
     const int nout = nfr * FB;
     for (int i = lane; i < nout; i += 64) { y[i] = s_tr[i]; }
+}
+
+typedef void (*kernel_fn)(const FastParams);
+
+kernel_fn spectrogram_kernel_for(int nz)
+{
+    switch (nz)
+    {
+        case 9: return fast_spectrogram_kernel<9>;
+        case 10: return fast_spectrogram_kernel<10>;
+        case 11: return fast_spectrogram_kernel<11>;
+        case 12: return fast_spectrogram_kernel<12>;
+        case 13: return fast_spectrogram_kernel<13>;
+        case 14: return fast_spectrogram_kernel<14>;
+        case 15: return fast_spectrogram_kernel<15>;
+        default: return fast_spectrogram_kernel<16>;
+    }
 }
 
 }  // namespace
@@ -287,7 +342,7 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
     if (o.dtype != SPEECH_F32 || nfft != (size_t)NFFT) { return false; }
     if ((float)o.dither > FLT_EPSILON) { return false; }                    // dither runs on the generic kernel
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
-    if (stp < 1u || stp > 1024u || L > (size_t)NFFT) { return false; }
+    if (stp < 2u || stp > 1024u || (stp & 1u) || L > (size_t)NFFT || L <= (size_t)NFFT / 2u) { return false; }
     return o.kind == SPEECH_SPECTROGRAM;
 }
 
@@ -308,7 +363,7 @@ FastTables *fast_tables_create(const speech_opts &, size_t L, size_t, size_t, si
         tab[TAB_TW2 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[TAB_TW2 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
     FastTables *t = new (std::nothrow) FastTables();
     if (!t) { if (err) { *err = "out of host memory"; } return nullptr; }
-    t->d_tab = nullptr;
+    t->d_tab = nullptr; t->nz = (int)((L + 31u) / 32u); t->attr_set = false;
     hipError_t e = hipMalloc((void **)&t->d_tab, tab.size() * sizeof(float));
     if (e == hipSuccess) { e = hipMemcpy(t->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); }
     if (e != hipSuccess) { if (err) { *err = hipGetErrorString(e); } fast_tables_destroy(t); return nullptr; }
@@ -330,19 +385,20 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     FastParams p;
     p.X = fp.X; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
-    p.span = ((QF - 1) * fp.stp + NFFT + 3) & ~3;
+    p.span = ((QF - 1) * fp.stp + 32 * t->nz + 3) & ~3;
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.tab = t->d_tab;
-    const size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * (p.span + TR_FLOATS)) * sizeof(float);
+    const size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * (p.span + TR_WAVE)) * sizeof(float);
+    kernel_fn k = spectrogram_kernel_for(t->nz);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
     {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fast_spectrogram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { return e; }
     }
     if (ev0) { e = hipEventRecord(ev0, s); if (e != hipSuccess) { return e; } }
-    hipLaunchKernelGGL(fast_spectrogram_kernel, dim3(fp.ntiles), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL(k, dim3(fp.ntiles), dim3(NT), lds, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) { return e; }
     if (ev1) { e = hipEventRecord(ev1, s); }
