@@ -24,14 +24,22 @@
 //              bases followed by one lane per frame running Levinson-Durbin and the cepstral recursion.
 #include "speech_internal.hpp"
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 
 namespace speech {
 
+constexpr int MAX_MTILES = 6;            // mel / cepstral tiles of 16 columns (B, C <= 96)
+
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[9][16] complex
+    float *d_melw;     // banded mel matrix: per 16-mel tile, [4 * ksteps][16] weights of FFT bins kbeg .. kbeg + 4 ksteps - 1
+    float *d_mat2;     // mfcc: lifter-scaled DCT matrix [Bp4][Cp]; plp: IDFT bases [K4][16]
+    float *d_aux;      // plp: eql[B] | lift[C]
     int nz;            // ceil(L / 32): rows of 32 samples that hold data
-    bool attr_set;
+    int kind, B, C, P, D, MP, Cp, K2, ntile_m, ntile_c;
+    int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES];
 };
 void fast_tables_destroy(FastTables *t);
 
@@ -55,7 +63,15 @@ struct FastParams {
     int snip_edges, dc0, want_pre, want_post;
     float preemph;                      // 0 when pre-emphasis is off
     const float *tab;
+    // mel kinds
+    const float *melw, *mat2, *aux;
+    int B, C, MP, Cp, K2, ntile_m, ntile_c;
+    int amp, lg, use_energy, compress_mode;
+    float compress;
+    int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES];
 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -123,10 +139,16 @@ __device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16])
     for (int b = 0; b < 4; ++b) { fft4(re[4 * b], im[4 * b], re[4 * b + 1], im[4 * b + 1], re[4 * b + 2], im[4 * b + 2], re[4 * b + 3], im[4 * b + 3]); }
 }
 
-__device__ __forceinline__ float floor_log(float v)
+// natural log of a positive normal float: exponent and mantissa split so that v_log_f32 (1 ulp on log2) only sees
+// [0.5, 1): absolute error ~5e-8 plus the final rounding, instead of 1 ulp of log2(x) ~ 2e-6 at x ~ 1e9
+__device__ __forceinline__ float pos_log(float v)
 {
-    return __log2f(fmaxf(v, FLT_EPSILON)) * 0.69314718055994530942f;
+    const float m = __builtin_amdgcn_frexp_mantf(v);
+    const float e = (float)__builtin_amdgcn_frexp_expf(v);
+    return fmaf(e, 0.69314718055994530942f, __log2f(m) * 0.69314718055994530942f);
 }
+
+__device__ __forceinline__ float floor_log(float v) { return pos_log(fmaxf(v, FLT_EPSILON)); }
 
 // Load the wave's audio slice: `need` samples starting at utterance-relative position s0 (may be negative or run past N
 // when snip_edges is off: reflected as c/kaldi_mfcc.c:228).  All arguments but `lane` are wave-uniform.
@@ -318,22 +340,230 @@ __global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p
     for (int i = lane; i < nout; i += 64) { y[i] = s_tr[i]; }
 }
 
+// One 16 x 16 output tile of  A[16 frames][K] . Bm[K][16]  on the matrix cores.  `arow` points at this lane's A element
+// of k-step 0 (LDS, row pitch chosen so that the 64 b32 reads of a step are conflict-free), `brow` at its Bm element
+// (global, L1/L2-resident; consecutive lanes read consecutive floats), `bstep` = floats between k-steps of Bm.
+// v_mfma_f32_16x16x4_f32 is an exact f32 fma chain in k order; two accumulators hide its 40-cycle dependent latency.
+__device__ __forceinline__ f32x4 mfma_tile(const float *arow, const float *brow, const int bstep, const int ksteps)
+{
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    int s = 0;
+    for (; s + 1 < ksteps; s += 2)
+    {
+        const float a0 = arow[4 * s], b0 = brow[(size_t)s * bstep];
+        const float a1 = arow[4 * s + 4], b1 = brow[(size_t)(s + 1) * bstep];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    }
+    if (s < ksteps) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * s], brow[(size_t)s * bstep], acc0, 0, 0, 0); }
+    return acc0 + acc1;
+}
+
+// fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
+// Levinson-Durbin and the cepstral recursion stay in registers).
+template <int NZ, int KIND, int P>
+__global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *s_tab = smem;
+    float *s_aud = smem + TAB_FLOATS + wv * p.span;
+    float *s_pow = smem + TAB_FLOATS + (NT / 64) * p.span;                  // 16 x PP power tile = the four transposition slices
+    float *s_tr = s_pow + wv * TR_WAVE;
+    // after the front end the four audio slices are dead and hold: frame energies | output tile | mel tile | autocorrelations
+    float *s_e = smem + TAB_FLOATS;
+    float *s_out = s_e + 16;
+    float *s_mel = s_out + ((16 * p.D + 3) & ~3);
+    float *s_ac = s_mel + 16 * p.MP;
+    for (int i = tid; i < TAB_FLOATS; i += NT) { s_tab[i] = p.tab[i]; }
+
+    const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
+    const UttDesc utt = p.utts[tile.utt];
+    const int fq = wv * QF;
+    const int nfr = min((int)tile.nframes - fq, QF);
+    if (nfr > 0)
+    {
+        const long long w0 = (long long)tile.frame0 + fq;
+        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
+        load_span(s_aud, p.X + utt.x_off, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
+    }
+    __syncthreads();
+
+    const int f = lane >> 4, k2 = lane & 15;
+    float pa[9], pb[9], rawe = 1.0f;
+    if (nfr > 0) { frame_power<NZ>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe); }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
+    }
+    __syncthreads();                                                        // every wave is done with its audio and transposition slices
+
+    // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> 16 x 257 tile, column 257 zero
+    {
+        float *pr = s_pow + (fq + f) * PP;
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+        {
+            pr[k2 + 16 * k1] = p.amp ? __fsqrt_rn(pa[k1]) : pa[k1];
+            pr[NC - 16 * k1 - k2] = p.amp ? __fsqrt_rn(pb[k1]) : pb[k1];
+        }
+        if (k2 == 0) { pr[128] = p.amp ? __fsqrt_rn(pa[8]) : pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }
+    }
+    __syncthreads();
+
+    // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
+    const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
+    const int fr0 = (lane >> 4) * 4, col = lane & 15;
+    for (int t = wv; t < p.ntile_m; t += NT / 64)
+    {
+        const f32x4 acc = mfma_tile(s_pow + col * PP + p.mel_kbeg[t] + (lane >> 4), p.melw + p.mel_woff[t] + lane, 64, p.mel_ksteps[t]);
+        const int m = 16 * t + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const int fr = fr0 + r;
+            const float v = acc[r];
+            if (KIND == SPEECH_FBANK)
+            {
+                if (m < p.B) { s_out[fr * p.D + eo + m] = p.lg ? floor_log(v) : v; }        // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column)
+            }
+            else if (KIND == SPEECH_MFCC)
+            {
+                if (m < p.K2) { s_mel[fr * p.MP + m] = (m < p.B) ? floor_log(v) : 0.0f; }   // c/kaldi_mfcc.c:318
+            }
+            else
+            {
+                // equal loudness, compression, end duplication (c/kaldi_plp.c:339-358)
+                if (m < p.B)
+                {
+                    const float x = v * p.aux[m];
+                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : __builtin_amdgcn_exp2f(p.compress * __log2f(x)));
+                    s_mel[fr * p.MP + 1 + m] = c;
+                    if (m == 0) { s_mel[fr * p.MP] = c; }
+                    if (m == p.B - 1) { for (int j = p.B + 1; j < p.K2; ++j) { s_mel[fr * p.MP + j] = (j == p.B + 1) ? c : 0.0f; } }
+                }
+            }
+        }
+    }
+    if (KIND == SPEECH_FBANK && eo && tid < 16) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
+    __syncthreads();
+
+    if (KIND == SPEECH_MFCC)
+    {
+        // DCT-II x lifter as a second contraction (c/kaldi_mfcc.c:323-333); the last-cepstrum quirk is a duplicated column
+        for (int t = wv; t < p.ntile_c; t += NT / 64)
+        {
+            const f32x4 acc = mfma_tile(s_mel + col * p.MP + (lane >> 4), p.mat2 + (lane >> 4) * p.Cp + 16 * t + col, 4 * p.Cp, p.K2 >> 2);
+            const int c = 16 * t + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int fr = fr0 + r;
+                if (c < p.C) { s_out[fr * p.C + c] = (p.use_energy && c == 0) ? pos_log(s_e[fr]) : acc[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    if (KIND == SPEECH_PLP)
+    {
+        // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile, wave 0
+        if (wv == 0)
+        {
+            const f32x4 acc = mfma_tile(s_mel + col * p.MP + (lane >> 4), p.mat2 + lane, 64, p.K2 >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s_ac[(fr0 + r) * 17 + col] = acc[r]; }
+        }
+        __syncthreads();
+        if (tid < 16)
+        {
+            // one lane per frame: Levinson-Durbin with Kaldi's 1 - k^2 >= 1e-5 guard, LPC -> cepstrum, lifter
+            // (reference intent c/kaldi_plp.c:206,380-403)
+            const float *r = s_ac + tid * 17;
+            float a[P > 0 ? P : 1], tmp[P > 0 ? P : 1], cep[P > 0 ? P : 1];
+            float E = r[0];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                float ki = r[i + 1];
+#pragma unroll
+                for (int j = 0; j < i; ++j) { ki += a[j] * r[i - j]; }
+                ki = ki / E;
+                float c = 1.0f - ki * ki;
+                c = (c < 1.0e-5f) ? 1.0e-5f : c;
+                E *= c;
+                tmp[i] = -ki;
+#pragma unroll
+                for (int j = 0; j < i; ++j) { tmp[j] = a[j] - ki * a[i - j - 1]; }
+#pragma unroll
+                for (int j = 0; j <= i; ++j) { a[j] = tmp[j]; }
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < i; ++j) { sum += (float)(i - j) * a[j] * cep[i - j - 1]; }
+                cep[i] = -a[i] - sum / (float)(i + 1);
+            }
+            const float *lift = p.aux + p.B;
+            float *y = s_out + tid * p.C;
+            const int C = p.C;
+            float prev = 0.0f;
+#pragma unroll
+            for (int k = 0; k <= P; ++k)
+            {
+                if (k < C)
+                {
+                    float v = (k == 0) ? floor_log(E) : cep[k > 0 ? k - 1 : 0];
+                    v *= lift[k];
+                    if (k == 0 && p.use_energy) { v = pos_log(s_e[tid]); }     // c/kaldi_plp.c:397
+                    if (k == C - 1 && C >= 2) { v = prev; }                                               // c/kaldi_plp.c:403
+                    y[k] = v; prev = v;
+                }
+            }
+            for (int k = P + 1; k < C; ++k) { const float v = (k == C - 1) ? prev : 0.0f; y[k] = v; prev = v; }
+        }
+        __syncthreads();
+    }
+
+    // the tile's nframes x D outputs are one contiguous run of Y
+    float *y = p.Y + utt.y_off + (unsigned long long)tile.frame0 * (unsigned long long)p.D;
+    const int nout = (int)tile.nframes * p.D;
+    for (int i = tid; i < nout; i += NT) { y[i] = s_out[i]; }
+}
+
 typedef void (*kernel_fn)(const FastParams);
 
-kernel_fn spectrogram_kernel_for(int nz)
+template <int NZ>
+kernel_fn kernel_for_kind(int kind)
+{
+    switch (kind)
+    {
+        case SPEECH_SPECTROGRAM: return fast_spectrogram_kernel<NZ>;
+        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0>;
+        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0>;
+        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12>;
+    }
+}
+
+kernel_fn kernel_for(int nz, int kind)
 {
     switch (nz)
     {
-        case 9: return fast_spectrogram_kernel<9>;
-        case 10: return fast_spectrogram_kernel<10>;
-        case 11: return fast_spectrogram_kernel<11>;
-        case 12: return fast_spectrogram_kernel<12>;
-        case 13: return fast_spectrogram_kernel<13>;
-        case 14: return fast_spectrogram_kernel<14>;
-        case 15: return fast_spectrogram_kernel<15>;
-        default: return fast_spectrogram_kernel<16>;
+        case 9: return kernel_for_kind<9>(kind);
+        case 10: return kernel_for_kind<10>(kind);
+        case 11: return kernel_for_kind<11>(kind);
+        case 12: return kernel_for_kind<12>(kind);
+        case 13: return kernel_for_kind<13>(kind);
+        case 14: return kernel_for_kind<14>(kind);
+        case 15: return kernel_for_kind<15>(kind);
+        default: return kernel_for_kind<16>(kind);
     }
 }
+
+int mel_pitch(int cols) { return 32 * ((cols + 31) / 32) + 2; }              // = 2 (mod 32): the MFMA A-operand reads are conflict-free
 
 }  // namespace
 
@@ -343,15 +573,40 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
     if ((float)o.dither > FLT_EPSILON) { return false; }                    // dither runs on the generic kernel
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > (size_t)NFFT || L <= (size_t)NFFT / 2u) { return false; }
-    return o.kind == SPEECH_SPECTROGRAM;
+    if (o.kind == SPEECH_SPECTROGRAM) { return true; }
+    if (o.B < 2u || o.B > 16u * MAX_MTILES - 2u) { return false; }
+    size_t D = o.B + (o.use_energy ? 1u : 0u), cols = 0;
+    if (o.kind == SPEECH_MFCC) { if (o.C > 16u * MAX_MTILES) { return false; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
+    if (o.kind == SPEECH_PLP)
+    {
+        const size_t P = (o.lpc_order > 0u) ? o.lpc_order : o.C - 1u;
+        if (P != 12u) { return false; }                                     // the in-register Levinson-Durbin is built for order 12
+        D = o.C; cols = (o.B + 2u + 3u) & ~(size_t)3;
+    }
+    // the output / mel / autocorrelation tiles reuse the four audio slices
+    const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 3u) & ~(size_t)3;
+    const size_t need = 16u + ((16u * D + 3u) & ~(size_t)3) + 16u * (size_t)mel_pitch((int)cols) + 16u * 17u;
+    return need <= (NT / 64) * span;
 }
 
 int fast_tile_frames(const speech_opts &) { return TILE; }
 
-FastTables *fast_tables_create(const speech_opts &, size_t L, size_t, size_t, size_t, size_t, size_t, const std::vector<float> &win,
-                               const std::vector<float> &, const std::vector<int> &, const std::vector<int> &, const std::vector<float> &,
-                               const std::vector<float> &, const std::vector<float> &, const std::vector<float> &, std::string *err)
+static hipError_t upload_floats(const std::vector<float> &h, float **d)
 {
+    *d = nullptr;
+    if (h.empty()) { return hipSuccess; }
+    hipError_t e = hipMalloc((void **)d, h.size() * sizeof(float));
+    if (e == hipSuccess) { e = hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice); }
+    return e;
+}
+
+// Returns nullptr with *err empty when the option set turns out not to fit the tuned kernels (the plan then uses the
+// generic kernels), nullptr with a message on a real failure.
+FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, size_t B, size_t C, size_t P, const std::vector<float> &win,
+                               const std::vector<float> &f2b, const std::vector<int> &beg, const std::vector<int> &num, const std::vector<float> &dct,
+                               const std::vector<float> &lift, const std::vector<float> &eql, const std::vector<float> &idft, std::string *err)
+{
+    if (err) { err->clear(); }
     std::vector<float> tab(TAB_FLOATS, 0.0f);
     for (size_t l = 0; l < L && l < (size_t)NFFT; ++l) { tab[TAB_WIN + l] = win[l]; }
     const long double pi = 3.141592653589793238462643383279502884L;
@@ -363,9 +618,64 @@ FastTables *fast_tables_create(const speech_opts &, size_t L, size_t, size_t, si
         tab[TAB_TW2 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[TAB_TW2 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
     FastTables *t = new (std::nothrow) FastTables();
     if (!t) { if (err) { *err = "out of host memory"; } return nullptr; }
-    t->d_tab = nullptr; t->nz = (int)((L + 31u) / 32u); t->attr_set = false;
-    hipError_t e = hipMalloc((void **)&t->d_tab, tab.size() * sizeof(float));
-    if (e == hipSuccess) { e = hipMemcpy(t->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); }
+    t->d_tab = t->d_melw = t->d_mat2 = t->d_aux = nullptr;
+    t->nz = (int)((L + 31u) / 32u); t->kind = o.kind;
+    t->B = t->C = t->P = t->MP = t->Cp = t->K2 = t->ntile_m = t->ntile_c = 0;
+    t->D = FB;
+    std::vector<float> melw, mat2, aux;
+    if (o.kind != SPEECH_SPECTROGRAM)
+    {
+        const int Bi = (int)B, Ci = (int)C;
+        t->B = Bi; t->ntile_m = (Bi + 15) / 16;
+        std::vector<int> off(B, 0);
+        for (size_t b = 1; b < B; ++b) { off[b] = off[b - 1] + num[b - 1]; }
+        for (int tl = 0; tl < t->ntile_m; ++tl)
+        {
+            // effective source bin of each column: fbank's last column is a copy of the one before (c/kaldi_fbank.c:350)
+            int src[16], kmin = 1 << 30, kmax = -1;
+            for (int c = 0; c < 16; ++c)
+            {
+                const int m = 16 * tl + c;
+                src[c] = (m < Bi) ? ((o.kind == SPEECH_FBANK && m == Bi - 1) ? Bi - 2 : m) : -1;
+                if (src[c] >= 0 && num[src[c]] > 0) { kmin = std::min(kmin, beg[src[c]]); kmax = std::max(kmax, beg[src[c]] + num[src[c]]); }
+            }
+            int ks = 0, kb = 0;
+            if (kmax > kmin) { ks = (kmax - kmin + 3) / 4; kb = kmin; if (kb + 4 * ks > PP) { kb = PP - 4 * ks; } }
+            if (kb < 0) { delete t; return nullptr; }                       // a tile spanning more than 256 bins: generic kernels
+            t->mel_kbeg[tl] = kb; t->mel_ksteps[tl] = ks; t->mel_woff[tl] = (int)melw.size();
+            melw.resize(melw.size() + (size_t)64 * ks, 0.0f);
+            float *w = melw.data() + t->mel_woff[tl];
+            for (int c = 0; c < 16; ++c)
+            {
+                if (src[c] < 0) { continue; }
+                for (int j = 0; j < num[src[c]]; ++j) { w[(beg[src[c]] + j - kb) * 16 + c] = f2b[off[src[c]] + j]; }
+            }
+        }
+        if (melw.empty()) { melw.push_back(0.0f); }
+        t->D = Bi + (o.use_energy ? 1 : 0);
+        if (o.kind == SPEECH_MFCC)
+        {
+            // M[b][c] = lift[c] * 2 cos(pi (b + 1/2) c / B); column C-1 := column C-2 (c/kaldi_mfcc.c:333)
+            t->C = Ci; t->D = Ci; t->ntile_c = (Ci + 15) / 16; t->Cp = 16 * t->ntile_c; t->K2 = (Bi + 3) & ~3;
+            mat2.assign((size_t)t->K2 * t->Cp, 0.0f);
+            for (int b = 0; b < Bi; ++b) { for (int c = 0; c < Ci; ++c) {
+                const int ce = (c == Ci - 1 && Ci >= 2) ? Ci - 2 : c;
+                mat2[(size_t)b * t->Cp + c] = lift[ce] * dct[(size_t)ce * B + b]; } }
+        }
+        if (o.kind == SPEECH_PLP)
+        {
+            t->C = Ci; t->D = Ci; t->P = (int)P; t->K2 = (Bi + 2 + 3) & ~3;
+            mat2.assign((size_t)t->K2 * 16, 0.0f);
+            for (int i = 0; i <= (int)P && i < 16; ++i) { for (int j = 0; j < Bi + 2; ++j) { mat2[(size_t)j * 16 + i] = idft[(size_t)i * (B + 2) + j]; } }
+            aux.assign(eql.begin(), eql.end());
+            aux.insert(aux.end(), lift.begin(), lift.end());
+        }
+        t->MP = mel_pitch(t->K2);
+    }
+    hipError_t e = upload_floats(tab, &t->d_tab);
+    if (e == hipSuccess) { e = upload_floats(melw, &t->d_melw); }
+    if (e == hipSuccess) { e = upload_floats(mat2, &t->d_mat2); }
+    if (e == hipSuccess) { e = upload_floats(aux, &t->d_aux); }
     if (e != hipSuccess) { if (err) { *err = hipGetErrorString(e); } fast_tables_destroy(t); return nullptr; }
     return t;
 }
@@ -374,6 +684,9 @@ void fast_tables_destroy(FastTables *t)
 {
     if (!t) { return; }
     if (t->d_tab) { (void)hipFree(t->d_tab); }
+    if (t->d_melw) { (void)hipFree(t->d_melw); }
+    if (t->d_mat2) { (void)hipFree(t->d_mat2); }
+    if (t->d_aux) { (void)hipFree(t->d_aux); }
     delete t;
 }
 
@@ -383,14 +696,19 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
 {
     if (fp.ntiles == 0) { return hipSuccess; }
     FastParams p;
+    memset(&p, 0, sizeof(p));
     p.X = fp.X; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     p.span = ((QF - 1) * fp.stp + 32 * t->nz + 3) & ~3;
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.tab = t->d_tab;
+    p.melw = t->d_melw; p.mat2 = t->d_mat2; p.aux = t->d_aux;
+    p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;
+    p.amp = fp.amp; p.lg = fp.lg; p.use_energy = fp.use_energy; p.compress_mode = fp.compress_mode; p.compress = fp.compress;
+    for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; }
     const size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * (p.span + TR_WAVE)) * sizeof(float);
-    kernel_fn k = spectrogram_kernel_for(t->nz);
+    kernel_fn k = kernel_for(t->nz, t->kind);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
     {

@@ -304,8 +304,8 @@ int plan_build<float>(speech_plan *p)
     {
         std::string err;
         p->fast = fast_tables_create(p->o, p->sz.L, p->sz.stp, p->sz.nfft, p->o.B, p->o.C, p->P, t.win, t.f2b, t.beg, t.num, t.dct, t.lift, t.eql, t.idft, &err);
-        if (!p->fast) { return fail("speech_plan_create", "tuned-kernel tables: %s", err.c_str()); }
-        p->tuned = true;
+        if (!p->fast && !err.empty()) { return fail("speech_plan_create", "tuned-kernel tables: %s", err.c_str()); }
+        p->tuned = (p->fast != nullptr);                 // declined without a message: this option set runs on the generic kernels
     }
     return 0;
 }
