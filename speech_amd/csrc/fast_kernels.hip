@@ -50,8 +50,9 @@ constexpr int QF = 4;                   // frames per wave (quad)
 constexpr int TILE = 16;                // frames per workgroup
 constexpr int NFFT = 512, NC = 256, FB = 257;
 constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 9 * 16 * 2;
-constexpr int TR_WAVE = 1032;           // floats of a wave's transposition slice: 4 frames x 256 (+8 so that 4 x 257 outputs fit)
-constexpr int PP = 258;                 // pitch of the 16 x 257 power tile that aliases the four slices (4 x 1032 = 16 x 258)
+constexpr int TR_WAVE = 2048;           // floats of a wave's transposition image: 4 frames x 16 x 16 complex
+constexpr int PP = 258;                 // pitch of the 16 x 257 power tile (= 2 mod 32: conflict-free MFMA operand reads)
+constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
 struct FastParams {
     const float *X;
@@ -59,7 +60,7 @@ struct FastParams {
     const UttDesc *utts;
     const TileDesc *tiles;
     uint32_t ntiles;
-    int L, stp, D, span;                // span: floats of a wave's audio slice (multiple of 4)
+    int L, stp, D, span, ws;            // span: floats of a quad's audio; ws: floats of a wave's LDS slice (>= span, TR_WAVE)
     int snip_edges, dc0, want_pre, want_post;
     float preemph;                      // 0 when pre-emphasis is off
     const float *tab;
@@ -98,45 +99,79 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// forward 4-point DFT in place: (a,b,c,d) = x0..x3 -> X0..X3
-__device__ __forceinline__ void fft4(float &ar, float &ai, float &br, float &bi, float &cr, float &ci, float &dr, float &di)
+// ---- packed f32 arithmetic ------------------------------------------------------------------------------------
+// A wave64 f32 VALU instruction occupies its SIMD for 4 cycles whether it is v_fma_f32 or v_pk_fma_f32 (measured:
+// tools/ubench/valu_rate.hip, 70 vs 130 TFLOP/s), so complex numbers live in even-aligned VGPR pairs (re, im) and
+// every butterfly add, twiddle multiply and front-end step is one packed instruction.  hipcc does not fold the
+// (re, im) swaps and sign flips of complex arithmetic into the op_sel / neg modifiers of v_pk_*_f32, so those forms
+// are single-instruction asm statements (register operands only: no waits or hazards to manage).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ f2 add_mi(f2 a, f2 b)
 {
-    const float t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
-    const float t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
-    ar = t0r + t2r; ai = t0i + t2i;
-    cr = t0r - t2r; ci = t0i - t2i;
-    br = t1r + t3i; bi = t1i - t3r;
-    dr = t1r - t3i; di = t1i + t3r;
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
-__device__ __forceinline__ void cmul(float &r, float &i, const float wr, const float wi)
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2 add_pi(f2 a, f2 b)
 {
-    const float tr = r * wr - i * wi;
-    i = r * wi + i * wr;
-    r = tr;
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// a + conj(b) = (a.x + b.x, a.y - b.y)
+__device__ __forceinline__ f2 add_conj(f2 a, f2 b)
+{
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// -i (a - conj(b)) = (a.y + b.y, b.x - a.x)
+__device__ __forceinline__ f2 mi_sub_conj(f2 a, f2 b)
+{
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// complex product z w = (z.x w.x - z.y w.y, z.y w.x + z.x w.y)
+__device__ __forceinline__ f2 cmul(f2 z, f2 w)
+{
+    f2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(z), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(z), "v"(w), "v"(t));
+    return d;
+}
+
+// forward 4-point DFT in place: (a,b,c,d) = x0..x3 -> X0..X3
+__device__ __forceinline__ void fft4(f2 &a, f2 &b, f2 &c, f2 &d)
+{
+    const f2 t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+    a = t0 + t2; c = t0 - t2;
+    b = add_mi(t1, t3); d = add_pi(t1, t3);
 }
 
 // position of output X[k] after fft16()
 __host__ __device__ constexpr int P16(int k) { return (k >> 2) + 4 * (k & 3); }
 
 // forward 16-point DFT on registers, input natural order, output X[k] at position P16(k)
-__device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16])
+__device__ __forceinline__ void fft16(f2 (&z)[16])
 {
     constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, H = 0.70710678118654752440f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { fft4(re[a], im[a], re[a + 4], im[a + 4], re[a + 8], im[a + 8], re[a + 12], im[a + 12]); }
+    for (int a = 0; a < 4; ++a) { fft4(z[a], z[a + 4], z[a + 8], z[a + 12]); }
     // position a + 4 kb  *=  W16^(a kb)
-    cmul(re[1 + 4], im[1 + 4], C1, -S1);                 // W^1
-    cmul(re[1 + 8], im[1 + 8], H, -H);                   // W^2
-    cmul(re[1 + 12], im[1 + 12], S1, -C1);               // W^3
-    cmul(re[2 + 4], im[2 + 4], H, -H);                   // W^2
-    { const float t = re[2 + 8]; re[2 + 8] = im[2 + 8]; im[2 + 8] = -t; }       // W^4 = -i
-    cmul(re[2 + 12], im[2 + 12], -H, -H);                // W^6
-    cmul(re[3 + 4], im[3 + 4], S1, -C1);                 // W^3
-    cmul(re[3 + 8], im[3 + 8], -H, -H);                  // W^6
-    cmul(re[3 + 12], im[3 + 12], -C1, S1);               // W^9
+    const f2 w1 = {C1, -S1}, w2 = {H, -H}, w3 = {S1, -C1}, w6 = {-H, -H}, w9 = {-C1, S1};
+    z[1 + 4] = cmul(z[1 + 4], w1); z[1 + 8] = cmul(z[1 + 8], w2); z[1 + 12] = cmul(z[1 + 12], w3);
+    z[2 + 4] = cmul(z[2 + 4], w2); z[2 + 8] = f2{z[2 + 8].y, -z[2 + 8].x}; z[2 + 12] = cmul(z[2 + 12], w6);
+    z[3 + 4] = cmul(z[3 + 4], w3); z[3 + 8] = cmul(z[3 + 8], w6); z[3 + 12] = cmul(z[3 + 12], w9);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { fft4(re[4 * b], im[4 * b], re[4 * b + 1], im[4 * b + 1], re[4 * b + 2], im[4 * b + 2], re[4 * b + 3], im[4 * b + 3]); }
+    for (int b = 0; b < 4; ++b) { fft4(z[4 * b], z[4 * b + 1], z[4 * b + 2], z[4 * b + 3]); }
 }
 
 // natural log of a positive normal float: exponent and mantissa split so that v_log_f32 (1 ulp on log2) only sees
@@ -150,14 +185,27 @@ __device__ __forceinline__ float pos_log(float v)
 
 __device__ __forceinline__ float floor_log(float v) { return pos_log(fmaxf(v, FLT_EPSILON)); }
 
+// spectrogram: log(max(q / 4, FLT_EPSILON)) with v_log_f32 on the whole value (absolute error ~2e-6 at q ~ 1e9; the
+// spectrogram tolerance is 1e-5) -- three instructions per bin
+__device__ __forceinline__ float spec_log(float q)
+{
+    return fmaf(__log2f(fmaxf(q, 4.0f * FLT_EPSILON)), 0.69314718055994530942f, -1.38629436111989061883f);
+}
+
 // Load the wave's audio slice: `need` samples starting at utterance-relative position s0 (may be negative or run past N
 // when snip_edges is off: reflected as c/kaldi_mfcc.c:228).  All arguments but `lane` are wave-uniform.
+// Interior quads use raw buffer loads: 256 B per wave-instruction, lane offset in one VGPR, the step in an SGPR, and
+// the descriptor's range check instead of a per-lane bound test.
 __device__ __forceinline__ void load_span(float *s_aud, const float *xu, long long s0, int need, long long N, int lane)
 {
     if (s0 >= 0 && s0 + need <= N)
     {
-        const float *src = xu + s0;
-        for (int i = lane; i < need; i += 64) { s_aud[i] = src[i]; }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
+        const int nit = (need + 63) >> 6;
+        for (int j = 0; j < nit; ++j)
+        {
+            s_aud[lane + 64 * j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0));
+        }
     }
     else
     {
@@ -170,11 +218,24 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, long lo
     }
 }
 
+// Store `nout` floats of the wave's LDS staging to y (contiguous), 256 B per wave-instruction.
+__device__ __forceinline__ void store_run(float *y, const float *s_src, int nout, int lane)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, nout * 4, BUF_FLAGS);
+    const int nit = (nout + 63) >> 6;
+    for (int j = 0; j < nit; ++j)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s_src[lane + 64 * j]), rs, lane * 4, j * 256, 0);
+    }
+}
+
 // One frame per 16-lane row: front end + 512-point real FFT + power.  NZ = ceil(L / 32): rows n2 < NZ-1 are full,
 // row NZ-1 is cut at L, rows >= NZ are the zero padding (never read, folded at compile time).
-// `fa` (8-byte aligned) is the frame's first sample in the wave's audio slice, `s_tr` the wave's transposition slice.
+// `fa` (8-byte aligned) is the frame's first sample in the wave's LDS slice; `s_tr` is that same slice, reused for the
+// transposition once the samples are in registers.
 // On return lane k2 (= lane & 15) holds, for k1 = 0..7 (and k1 = 8, meaningful in lane k2 == 0 only):
-//   pa[k1] = |X[k]|^2, pb[k1] = |X[256 - k]|^2 with k = k2 + 16 k1;   rawe = the frame's (floored) energy.
+//   pa[k1] = 4 |X[k]|^2, pb[k1] = 4 |X[256 - k]|^2 with k = k2 + 16 k1 (the factor 4 is folded into what consumes them);
+//   rawe = the frame's (floored) energy.
 template <int NZ>
 __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
                                             float (&pa)[9], float (&pb)[9], float &rawe)
@@ -183,102 +244,87 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
     const int L = p.L;
     const int llast = 2 * n1 + 32 * (NZ - 1);
     const bool ve = llast < L, vo = llast + 1 < L;                          // validity of the lane's two samples in row NZ-1
-    float re[16], im[16];
-    float sum = 0.0f;
+    f2 z[16];
+    f2 sum2 = {0.0f, 0.0f};
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2)
     {
         if (n2 < NZ)
         {
-            const float2 v = *reinterpret_cast<const float2 *>(fa + 2 * n1 + 32 * n2);
-            re[n2] = (n2 < NZ - 1 || ve) ? v.x : 0.0f;
-            im[n2] = (n2 < NZ - 1 || vo) ? v.y : 0.0f;
-            sum += re[n2]; sum += im[n2];
+            f2 v = *reinterpret_cast<const f2 *>(fa + 2 * n1 + 32 * n2);
+            if (n2 == NZ - 1) { v.x = ve ? v.x : 0.0f; v.y = vo ? v.y : 0.0f; }
+            z[n2] = v;
+            sum2 += v;
         }
-        else { re[n2] = 0.0f; im[n2] = 0.0f; }
+        else { z[n2] = f2{0.0f, 0.0f}; }
     }
     float mean = 0.0f;
-    if (p.dc0) { mean = row16_sum(sum) / (float)L; }                        // c/kaldi_mfcc.c:265-271
-    const float pre = p.preemph;
-    const float2 *win = reinterpret_cast<const float2 *>(s_tab + TAB_WIN);
+    if (p.dc0) { mean = row16_sum(sum2.x + sum2.y) / (float)L; }            // c/kaldi_mfcc.c:265-271
+    const f2 mean2 = {mean, mean};
+    const f2 npre2 = {-p.preemph, -p.preemph};
+    const f2 *win = reinterpret_cast<const f2 *>(s_tab + TAB_WIN);
     const float *fprev = fa + ((n1 > 0) ? 2 * n1 - 1 : 0);                  // sample before the lane's even sample of row 0 (itself for l = 0)
-    float e = 0.0f;
+    f2 e2 = {0.0f, 0.0f};
 #pragma unroll
     for (int n2 = 0; n2 < NZ; ++n2)
     {
-        float de = re[n2] - mean, dq = im[n2] - mean;
-        if (n2 == NZ - 1) { de = ve ? de : 0.0f; dq = vo ? dq : 0.0f; }
-        if (p.want_pre) { e += de * de; e += dq * dq; }                     // c/kaldi_mfcc.c:274-279
+        f2 d = z[n2] - mean2;
+        if (n2 == NZ - 1) { d.x = ve ? d.x : 0.0f; d.y = vo ? d.y : 0.0f; }
+        if (p.want_pre) { e2 = __builtin_elementwise_fma(d, d, e2); }       // c/kaldi_mfcc.c:274-279
         // pre-emphasis: y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0]         c/kaldi_mfcc.c:282-288
-        const float xp = (n2 == 0) ? fprev[0] : fa[2 * n1 + 32 * n2 - 1];
-        const float2 w = win[n1 + 16 * n2];                                 // c/kaldi_mfcc.c:291 (table is zero beyond L)
-        float ye = (de - pre * (xp - mean)) * w.x;
-        float yo = (dq - pre * de) * w.y;
-        if (n2 == NZ - 1) { ye = ve ? ye : 0.0f; yo = vo ? yo : 0.0f; }     // the slice beyond the quad's last sample is not initialised
-        if (p.want_post) { e += ye * ye; e += yo * yo; }                    // c/kaldi_mfcc.c:295-301
-        re[n2] = ye; im[n2] = yo;
+        const f2 xp = {(n2 == 0) ? fprev[0] : fa[2 * n1 + 32 * n2 - 1], z[n2].x};
+        f2 y = __builtin_elementwise_fma(npre2, xp - mean2, d) * win[n1 + 16 * n2];     // window: c/kaldi_mfcc.c:291 (table is zero beyond L)
+        if (n2 == NZ - 1) { y.x = ve ? y.x : 0.0f; y.y = vo ? y.y : 0.0f; }             // the slice beyond the quad's last sample is not initialised
+        if (p.want_post) { e2 = __builtin_elementwise_fma(y, y, e2); }      // c/kaldi_mfcc.c:295-301
+        z[n2] = y;
     }
-    rawe = fmaxf(row16_sum(e), FLT_EPSILON);
+    rawe = fmaxf(row16_sum(e2.x + e2.y), FLT_EPSILON);
 
-    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS (swizzled: element (k2, n) of a frame
-    // lives at k2*16 + 4*((n>>2) ^ (k2>>2)) + (n&3))
-    fft16(re, im);
-    const float2 *tw1 = reinterpret_cast<const float2 *>(s_tab + TAB_TW1);
+    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS: complex element (k2, n) of a frame lives
+    // at float offset 32 k2 + 4 ((n>>1) ^ (k2>>1)) + 2 (n&1): b64 writes and b128 reads are both conflict-free
+    fft16(z);
+    const f2 *tw1 = reinterpret_cast<const f2 *>(s_tab + TAB_TW1);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2)
-    {
-        const float2 w = tw1[k2 * 16 + n1];
-        cmul(re[P16(k2)], im[P16(k2)], w.x, w.y);
-    }
-    float *trf = s_tr + f * 256;
-    int woff[4];
+    for (int k2 = 1; k2 < 16; ++k2) { z[P16(k2)] = cmul(z[P16(k2)], tw1[k2 * 16 + n1]); }
+    wave_sync();                                                            // every lane has its samples: the slice becomes the transposition image
+    float *trf = s_tr + f * 512;
+    const int wlo = 2 * (n1 & 1), wm = n1 >> 1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
+    for (int kk = 0; kk < 16; ++kk) { *reinterpret_cast<f2 *>(trf + 32 * kk + 4 * (wm ^ (kk >> 1)) + wlo) = z[P16(kk)]; }
+    wave_sync();
     const int k2 = n1;                                                      // the lane's role after the transpose
-    const float *rrow = trf + k2 * 16;
-    const int rq = k2 >> 2;
+    const float *rrow = trf + 32 * k2;
+    const int rg = k2 >> 1;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = re[P16(kk)]; }
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int m = 0; m < 8; ++m)
     {
-        const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
-        re[4 * q] = v.x; re[4 * q + 1] = v.y; re[4 * q + 2] = v.z; re[4 * q + 3] = v.w;
+        const float4 v = *reinterpret_cast<const float4 *>(rrow + 4 * (m ^ rg));
+        z[2 * m] = f2{v.x, v.y}; z[2 * m + 1] = f2{v.z, v.w};
     }
     wave_sync();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = im[P16(kk)]; }
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-    {
-        const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
-        im[4 * q] = v.x; im[4 * q + 1] = v.y; im[4 * q + 2] = v.z; im[4 * q + 3] = v.w;
-    }
-    wave_sync();
-    fft16(re, im);                                                          // Z[k2 + 16 k1] at position P16(k1)
+    fft16(z);                                                               // Z[k2 + 16 k1] at position P16(k1)
 
     // untangle: partner lane (16 - k2) mod 16 of the same row holds Z[256 - k] in register 15 - k1; lane 0 is its own
     // partner with register (16 - k1) mod 16
     const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
     const bool lane0 = (k2 == 0);
-    const float2 *tw2 = reinterpret_cast<const float2 *>(s_tab + TAB_TW2);
+    const f2 *tw2 = reinterpret_cast<const f2 *>(s_tab + TAB_TW2);
 #pragma unroll
     for (int k1 = 0; k1 < 9; ++k1)
     {
-        float zpr = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(re[P16((15 - k1) & 15)])));
-        float zpi = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(im[P16((15 - k1) & 15)])));
-        zpr = lane0 ? re[P16((16 - k1) & 15)] : zpr;
-        zpi = lane0 ? im[P16((16 - k1) & 15)] : zpi;
-        const float zkr = re[P16(k1)], zki = im[P16(k1)];
-        const float er = zkr + zpr, ei = zki - zpi;                         // 2E = Z[k] + conj Z[256-k]
-        float tr = zki + zpi, ti = zpr - zkr;                               // 2O = -i (Z[k] - conj Z[256-k])
-        const float2 w = tw2[k1 * 16 + k2];                                 // exp(-i pi k / 256)
-        cmul(tr, ti, w.x, w.y);
-        const float ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
-        pa[k1] = 0.25f * (ar * ar + ai * ai);
-        pb[k1] = 0.25f * (br * br + bi * bi);
+        const f2 zo = z[P16((15 - k1) & 15)], zs = z[P16((16 - k1) & 15)];
+        f2 zp;
+        zp.x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.x)));
+        zp.y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.y)));
+        zp.x = lane0 ? zs.x : zp.x;
+        zp.y = lane0 ? zs.y : zp.y;
+        const f2 zk = z[P16(k1)];
+        const f2 e = add_conj(zk, zp);                                      // 2E = Z[k] + conj Z[256-k]
+        const f2 t = cmul(mi_sub_conj(zk, zp), tw2[k1 * 16 + k2]);          // 2O exp(-i pi k / 256), 2O = -i (Z[k] - conj Z[256-k])
+        const f2 a = e + t, b = e - t;
+        const f2 qa = a * a, qb = b * b;
+        pa[k1] = qa.x + qa.y;
+        pb[k1] = qb.x + qb.y;
     }
 }
 
@@ -297,8 +343,8 @@ __global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
-    float *s_aud = smem + TAB_FLOATS + wv * p.span;
-    float *s_tr = smem + TAB_FLOATS + (NT / 64) * p.span + wv * TR_WAVE;
+    float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image, then output staging
+    float *s_tr = s_aud;
     for (int i = tid; i < TAB_FLOATS; i += NT) { s_tab[i] = p.tab[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
@@ -318,11 +364,12 @@ __global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p
     float pa[9], pb[9], rawe;
     frame_power<NZ>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
 
-    // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything
-    float *so = s_tr + f * FB;                                              // output staging aliases the transposition slice
+    // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything.
+    // pa/pb carry 4 |X|^2: log(max(q/4, eps)) = ln2 * log2(max(q, 4 eps)) - 2 ln2
+    float *so = s_tr + f * FB;                                              // output staging aliases the transposition image
     {
-        const float la = floor_log((k2 == 0) ? rawe : pa[0]);
-        const float lb = floor_log(pb[0]);
+        const float la = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
+        const float lb = spec_log(pb[0]);
         so[k2] = la;
         if (k2 > 0) { so[NC - k2] = lb; }
         if (k2 == 1) { so[NC] = lb; }
@@ -330,14 +377,12 @@ __global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1)
     {
-        so[k2 + 16 * k1] = floor_log(pa[k1]);
-        so[NC - 16 * k1 - k2] = floor_log(pb[k1]);
+        so[k2 + 16 * k1] = spec_log(pa[k1]);
+        so[NC - 16 * k1 - k2] = spec_log(pb[k1]);
     }
-    if (k2 == 0) { so[128] = floor_log(pa[8]); }
+    if (k2 == 0) { so[128] = spec_log(pa[8]); }
     wave_sync();
-    float *y = p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB;
-    const int nout = nfr * FB;
-    for (int i = lane; i < nout; i += 64) { y[i] = s_tr[i]; }
+    store_run(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB, s_tr, nfr * FB, lane);
 }
 
 // One 16 x 16 output tile of  A[16 frames][K] . Bm[K][16]  on the matrix cores.  `arow` points at this lane's A element
@@ -368,11 +413,11 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
-    float *s_aud = smem + TAB_FLOATS + wv * p.span;
-    float *s_pow = smem + TAB_FLOATS + (NT / 64) * p.span;                  // 16 x PP power tile = the four transposition slices
-    float *s_tr = s_pow + wv * TR_WAVE;
-    // after the front end the four audio slices are dead and hold: frame energies | output tile | mel tile | autocorrelations
-    float *s_e = smem + TAB_FLOATS;
+    float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image
+    float *s_tr = s_aud;
+    // after the FFTs the four slices are dead and hold: 16 x PP power tile | frame energies | output tile | mel tile | autocorrelations
+    float *s_pow = smem + TAB_FLOATS;
+    float *s_e = s_pow + 16 * PP;
     float *s_out = s_e + 16;
     float *s_mel = s_out + ((16 * p.D + 3) & ~3);
     float *s_ac = s_mel + 16 * p.MP;
@@ -398,7 +443,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
 #pragma unroll
         for (int i = 0; i < 9; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
     }
-    __syncthreads();                                                        // every wave is done with its audio and transposition slices
+    __syncthreads();                                                        // every wave is done with its slice
 
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> 16 x 257 tile, column 257 zero
     {
@@ -583,10 +628,10 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
         if (P != 12u) { return false; }                                     // the in-register Levinson-Durbin is built for order 12
         D = o.C; cols = (o.B + 2u + 3u) & ~(size_t)3;
     }
-    // the output / mel / autocorrelation tiles reuse the four audio slices
+    // the power / output / mel / autocorrelation tiles reuse the four wave slices
     const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 3u) & ~(size_t)3;
-    const size_t need = 16u + ((16u * D + 3u) & ~(size_t)3) + 16u * (size_t)mel_pitch((int)cols) + 16u * 17u;
-    return need <= (NT / 64) * span;
+    const size_t need = 16u * PP + 16u + ((16u * D + 3u) & ~(size_t)3) + 16u * (size_t)mel_pitch((int)cols) + 16u * 17u;
+    return need <= (NT / 64) * std::max(span, (size_t)TR_WAVE);
 }
 
 int fast_tile_frames(const speech_opts &) { return TILE; }
@@ -627,6 +672,8 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, s
     {
         const int Bi = (int)B, Ci = (int)C;
         t->B = Bi; t->ntile_m = (Bi + 15) / 16;
+        // the kernels hand over 4 |X|^2 (2 |X| with amp): the exact power-of-two factor is folded into the weights
+        const float wscale = (o.kind == SPEECH_FBANK && o.amp) ? 0.5f : 0.25f;
         std::vector<int> off(B, 0);
         for (size_t b = 1; b < B; ++b) { off[b] = off[b - 1] + num[b - 1]; }
         for (int tl = 0; tl < t->ntile_m; ++tl)
@@ -648,7 +695,7 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, s
             for (int c = 0; c < 16; ++c)
             {
                 if (src[c] < 0) { continue; }
-                for (int j = 0; j < num[src[c]]; ++j) { w[(beg[src[c]] + j - kb) * 16 + c] = f2b[off[src[c]] + j]; }
+                for (int j = 0; j < num[src[c]]; ++j) { w[(beg[src[c]] + j - kb) * 16 + c] = wscale * f2b[off[src[c]] + j]; }
             }
         }
         if (melw.empty()) { melw.push_back(0.0f); }
@@ -700,6 +747,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.X = fp.X; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     p.span = ((QF - 1) * fp.stp + 32 * t->nz + 3) & ~3;
+    p.ws = std::max(p.span, TR_WAVE);
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.tab = t->d_tab;
@@ -707,7 +755,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;
     p.amp = fp.amp; p.lg = fp.lg; p.use_energy = fp.use_energy; p.compress_mode = fp.compress_mode; p.compress = fp.compress;
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; }
-    const size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * (p.span + TR_WAVE)) * sizeof(float);
+    const size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * p.ws) * sizeof(float);
     kernel_fn k = kernel_for(t->nz, t->kind);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)

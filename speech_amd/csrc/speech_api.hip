@@ -322,7 +322,7 @@ void fill_params(const speech_batch *b, const void *X, void *Y, FrameParams<T> *
     fp->L = (int)p->sz.L; fp->stp = (int)p->sz.stp; fp->nfft = (int)p->sz.nfft; fp->F = (int)p->sz.F; fp->log2n = p->sz.log2n;
     fp->D = (int)p->sz.D;
     fp->snip_edges = o.snip_edges ? 1 : 0; fp->dc0 = o.dc0 ? 1 : 0; fp->raw_energy = o.raw_energy ? 1 : 0;
-    fp->use_energy = o.use_energy ? 1 : 0; fp->amp = o.amp ? 1 : 0; fp->lg = o.lg ? 1 : 0;
+    fp->use_energy = o.use_energy ? 1 : 0; fp->amp = (o.kind == SPEECH_FBANK && o.amp) ? 1 : 0; fp->lg = o.lg ? 1 : 0;   // amp, lg: fbank only (c/kaldi_fbank.c:312-316)
     const bool spec = (o.kind == SPEECH_SPECTROGRAM);
     fp->want_pre = spec ? (o.raw_energy ? 1 : 0) : ((o.use_energy && o.raw_energy) ? 1 : 0);     // c/kaldi_spectrogram.c:203 vs c/kaldi_mfcc.c:274
     fp->want_post = spec ? (o.raw_energy ? 0 : 1) : ((o.use_energy && !o.raw_energy) ? 1 : 0);   // c/kaldi_spectrogram.c:224 vs c/kaldi_mfcc.c:295
