@@ -33,7 +33,7 @@ namespace speech {
 constexpr int MAX_MTILES = 6;            // mel / cepstral tiles of 16 columns (B, C <= 96)
 
 struct FastTables {
-    float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[9][16] complex
+    float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[8][16] complex
     float *d_melw;     // banded mel matrix: per 16-mel tile, [4 * ksteps][16] weights of FFT bins kbeg .. kbeg + 4 ksteps - 1
     float *d_mat2;     // mfcc: lifter-scaled DCT matrix [Bp4][Cp]; plp: IDFT bases [K4][16]
     float *d_aux;      // plp: eql[B] | lift[C]
@@ -49,8 +49,9 @@ constexpr int NT = 256;                 // threads per workgroup (4 waves)
 constexpr int QF = 4;                   // frames per wave (quad)
 constexpr int TILE = 16;                // frames per workgroup
 constexpr int NFFT = 512, NC = 256, FB = 257;
-constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 9 * 16 * 2;
-constexpr int TR_WAVE = 2048;           // floats of a wave's transposition image: 4 frames x 16 x 16 complex
+constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 8 * 16 * 2;
+constexpr int TR_WAVE = 1032;           // floats of a wave's LDS slice: 4 frames x 16 x 16 reals (transposition image of the real, then the
+                                        // imaginary parts), 4 x 257 outputs; four slices = the 16 x 258 power tile
 constexpr int PP = 258;                 // pitch of the 16 x 257 power tile (= 2 mod 32: conflict-free MFMA operand reads)
 constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
@@ -145,6 +146,21 @@ __device__ __forceinline__ f2 cmul(f2 z, f2 w)
     f2 t, d;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(z), "v"(w));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(z), "v"(w), "v"(t));
+    return d;
+}
+
+// (a.x, b.x) and (a.y, b.y): builds (re, im) pairs from a pair of reals and a pair of imaginaries in one instruction each
+__device__ __forceinline__ f2 pair_lo(f2 a, f2 b)
+{
+    f2 d;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+__device__ __forceinline__ f2 pair_hi(f2 a, f2 b)
+{
+    f2 d;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 
@@ -261,45 +277,71 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
     float mean = 0.0f;
     if (p.dc0) { mean = row16_sum(sum2.x + sum2.y) / (float)L; }            // c/kaldi_mfcc.c:265-271
     const f2 mean2 = {mean, mean};
-    const f2 npre2 = {-p.preemph, -p.preemph};
+    const float npre = -p.preemph;
     const f2 *win = reinterpret_cast<const f2 *>(s_tab + TAB_WIN);
     const float *fprev = fa + ((n1 > 0) ? 2 * n1 - 1 : 0);                  // sample before the lane's even sample of row 0 (itself for l = 0)
     f2 e2 = {0.0f, 0.0f};
 #pragma unroll
     for (int n2 = 0; n2 < NZ; ++n2)
     {
-        f2 d = z[n2] - mean2;
-        if (n2 == NZ - 1) { d.x = ve ? d.x : 0.0f; d.y = vo ? d.y : 0.0f; }
-        if (p.want_pre) { e2 = __builtin_elementwise_fma(d, d, e2); }       // c/kaldi_mfcc.c:274-279
+        z[n2] -= mean2;
+        if (n2 == NZ - 1) { z[n2].x = ve ? z[n2].x : 0.0f; z[n2].y = vo ? z[n2].y : 0.0f; }
+    }
+    if (p.want_pre)                                                         // c/kaldi_mfcc.c:274-279 (a wave-uniform branch, not a select per row)
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < NZ; ++n2)
+    {
         // pre-emphasis: y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0]         c/kaldi_mfcc.c:282-288
-        const f2 xp = {(n2 == 0) ? fprev[0] : fa[2 * n1 + 32 * n2 - 1], z[n2].x};
-        f2 y = __builtin_elementwise_fma(npre2, xp - mean2, d) * win[n1 + 16 * n2];     // window: c/kaldi_mfcc.c:291 (table is zero beyond L)
-        if (n2 == NZ - 1) { y.x = ve ? y.x : 0.0f; y.y = vo ? y.y : 0.0f; }             // the slice beyond the quad's last sample is not initialised
-        if (p.want_post) { e2 = __builtin_elementwise_fma(y, y, e2); }      // c/kaldi_mfcc.c:295-301
+        const float xpm = ((n2 == 0) ? fprev[0] : fa[2 * n1 + 32 * n2 - 1]) - mean;
+        f2 y;
+        y.x = fmaf(npre, xpm, z[n2].x);
+        y.y = fmaf(npre, z[n2].x, z[n2].y);
+        y *= win[n1 + 16 * n2];                                             // window: c/kaldi_mfcc.c:291 (table is zero beyond L)
+        if (n2 == NZ - 1) { y.x = ve ? y.x : 0.0f; y.y = vo ? y.y : 0.0f; } // the slice beyond the quad's last sample is not initialised
         z[n2] = y;
+    }
+    if (p.want_post)                                                        // c/kaldi_mfcc.c:295-301
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
     }
     rawe = fmaxf(row16_sum(e2.x + e2.y), FLT_EPSILON);
 
-    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS: complex element (k2, n) of a frame lives
-    // at float offset 32 k2 + 4 ((n>>1) ^ (k2>>1)) + 2 (n&1): b64 writes and b128 reads are both conflict-free
+    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS, real parts then imaginary parts (a 1 KB
+    // image per frame keeps 7 workgroups on a CU): element (k2, n) lives at 16 k2 + 4 ((n>>2) ^ (k2>>2)) + (n&3), which
+    // makes the b32 writes and the b128 reads conflict-free
     fft16(z);
     const f2 *tw1 = reinterpret_cast<const f2 *>(s_tab + TAB_TW1);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) { z[P16(k2)] = cmul(z[P16(k2)], tw1[k2 * 16 + n1]); }
     wave_sync();                                                            // every lane has its samples: the slice becomes the transposition image
-    float *trf = s_tr + f * 512;
-    const int wlo = 2 * (n1 & 1), wm = n1 >> 1;
+    float *trf = s_tr + f * 256;
+    int woff[4];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { *reinterpret_cast<f2 *>(trf + 32 * kk + 4 * (wm ^ (kk >> 1)) + wlo) = z[P16(kk)]; }
-    wave_sync();
+    for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
     const int k2 = n1;                                                      // the lane's role after the transpose
-    const float *rrow = trf + 32 * k2;
-    const int rg = k2 >> 1;
+    const float *rrow = trf + k2 * 16;
+    const int rq = k2 >> 2;
+    float4 rr[4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].x; }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { rr[q] = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2)); }
+    wave_sync();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].y; }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
     {
-        const float4 v = *reinterpret_cast<const float4 *>(rrow + 4 * (m ^ rg));
-        z[2 * m] = f2{v.x, v.y}; z[2 * m + 1] = f2{v.z, v.w};
+        const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
+        const f2 r01 = {rr[q].x, rr[q].y}, r23 = {rr[q].z, rr[q].w}, i01 = {v.x, v.y}, i23 = {v.z, v.w};
+        z[4 * q] = pair_lo(r01, i01); z[4 * q + 1] = pair_hi(r01, i01); z[4 * q + 2] = pair_lo(r23, i23); z[4 * q + 3] = pair_hi(r23, i23);
     }
     wave_sync();
     fft16(z);                                                               // Z[k2 + 16 k1] at position P16(k1)
@@ -309,8 +351,14 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
     const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
     const bool lane0 = (k2 == 0);
     const f2 *tw2 = reinterpret_cast<const f2 *>(s_tab + TAB_TW2);
+    {
+        // bin 128 (lane 0): Z[128] pairs with itself and exp(-i pi 128/256) = -i, so X[128] = conj Z[128]
+        const f2 q8 = z[P16(8)] * z[P16(8)];
+        pa[8] = 4.0f * (q8.x + q8.y);
+        pb[8] = pa[8];
+    }
 #pragma unroll
-    for (int k1 = 0; k1 < 9; ++k1)
+    for (int k1 = 0; k1 < 8; ++k1)
     {
         const f2 zo = z[P16((15 - k1) & 15)], zs = z[P16((16 - k1) & 15)];
         f2 zp;
@@ -365,24 +413,28 @@ __global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p
     frame_power<NZ>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
 
     // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything.
-    // pa/pb carry 4 |X|^2: log(max(q/4, eps)) = ln2 * log2(max(q, 4 eps)) - 2 ln2
-    float *so = s_tr + f * FB;                                              // output staging aliases the transposition image
+    // pa/pb carry 4 |X|^2: log(max(q/4, eps)) = ln2 * log2(max(q, 4 eps)) - 2 ln2.
+    // For each k1 the 16 lanes of a frame hold 16 consecutive bins: every store instruction writes four 64-byte runs, and
+    // consecutive instructions complete the 128-byte lines in L2.  The descriptor covers exactly the quad's nfr x 257
+    // outputs, so the rows of frames that do not exist are dropped by its range check.
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB), 0, nfr * FB * 4, BUF_FLAGS);
+    const int oup = (f * FB + k2) * 4;                                      // bins k2 + 16 k1, ascending
+    const int odn = (f * FB + NC - 112 - k2) * 4;                           // bins 256 - k2 - 16 k1, as 144 - k2 + 16 (7 - k1)
     {
         const float la = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
         const float lb = spec_log(pb[0]);
-        so[k2] = la;
-        if (k2 > 0) { so[NC - k2] = lb; }
-        if (k2 == 1) { so[NC] = lb; }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, la), ry, oup, 0, 0);
+        if (k2 > 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64, 0); }
+        if (k2 == 1) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64 + 4, 0); }      // bin 256 := bin 255
     }
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1)
     {
-        so[k2 + 16 * k1] = spec_log(pa[k1]);
-        so[NC - 16 * k1 - k2] = spec_log(pb[k1]);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[k1])), ry, oup, 64 * k1, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pb[k1])), ry, odn, 64 * (7 - k1), 0);
     }
-    if (k2 == 0) { so[128] = spec_log(pa[8]); }
-    wave_sync();
-    store_run(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB, s_tr, nfr * FB, lane);
+    if (k2 == 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[8])), ry, oup, 128 * 4, 0); }
 }
 
 // One 16 x 16 output tile of  A[16 frames][K] . Bm[K][16]  on the matrix cores.  `arow` points at this lane's A element
@@ -417,7 +469,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     float *s_tr = s_aud;
     // after the FFTs the four slices are dead and hold: 16 x PP power tile | frame energies | output tile | mel tile | autocorrelations
     float *s_pow = smem + TAB_FLOATS;
-    float *s_e = s_pow + 16 * PP;
+    float *s_e = smem + TAB_FLOATS + (NT / 64) * p.ws;                      // private region behind the slices
     float *s_out = s_e + 16;
     float *s_mel = s_out + ((16 * p.D + 3) & ~3);
     float *s_ac = s_mel + 16 * p.MP;
@@ -448,13 +500,19 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> 16 x 257 tile, column 257 zero
     {
         float *pr = s_pow + (fq + f) * PP;
+        if (p.amp)
+        {
+#pragma unroll
+            for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
+        }
+        float *pd = pr + (NC - 112 - k2);
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1)
         {
-            pr[k2 + 16 * k1] = p.amp ? __fsqrt_rn(pa[k1]) : pa[k1];
-            pr[NC - 16 * k1 - k2] = p.amp ? __fsqrt_rn(pb[k1]) : pb[k1];
+            pr[k2 + 16 * k1] = pa[k1];
+            pd[16 * (7 - k1)] = pb[k1];
         }
-        if (k2 == 0) { pr[128] = p.amp ? __fsqrt_rn(pa[8]) : pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }
+        if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }
     }
     __syncthreads();
 
@@ -630,8 +688,8 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
     }
     // the power / output / mel / autocorrelation tiles reuse the four wave slices
     const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 3u) & ~(size_t)3;
-    const size_t need = 16u * PP + 16u + ((16u * D + 3u) & ~(size_t)3) + 16u * (size_t)mel_pitch((int)cols) + 16u * 17u;
-    return need <= (NT / 64) * std::max(span, (size_t)TR_WAVE);
+    const size_t extra = 16u + ((16u * D + 3u) & ~(size_t)3) + 16u * (size_t)mel_pitch((int)cols) + 16u * 17u;
+    return (TAB_FLOATS + (NT / 64) * std::max(span, (size_t)TR_WAVE) + extra) * sizeof(float) <= 64u * 1024u;
 }
 
 int fast_tile_frames(const speech_opts &) { return TILE; }
@@ -658,7 +716,7 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, s
     for (int k2 = 0; k2 < 16; ++k2) { for (int n1 = 0; n1 < 16; ++n1) {
         const long double a = -2.0L * pi * (long double)(n1 * k2) / (long double)NC;
         tab[TAB_TW1 + (k2 * 16 + n1) * 2] = (float)cosl(a); tab[TAB_TW1 + (k2 * 16 + n1) * 2 + 1] = (float)sinl(a); } }
-    for (int k1 = 0; k1 < 9; ++k1) { for (int k2 = 0; k2 < 16; ++k2) {
+    for (int k1 = 0; k1 < 8; ++k1) { for (int k2 = 0; k2 < 16; ++k2) {
         const long double a = -pi * (long double)(k2 + 16 * k1) / (long double)NC;
         tab[TAB_TW2 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[TAB_TW2 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
     FastTables *t = new (std::nothrow) FastTables();
@@ -755,7 +813,8 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;
     p.amp = fp.amp; p.lg = fp.lg; p.use_energy = fp.use_energy; p.compress_mode = fp.compress_mode; p.compress = fp.compress;
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; }
-    const size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * p.ws) * sizeof(float);
+    size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * p.ws) * sizeof(float);
+    if (t->kind != SPEECH_SPECTROGRAM) { lds += (size_t)(16 + ((16 * t->D + 3) & ~3) + 16 * t->MP + 16 * 17) * sizeof(float); }
     kernel_fn k = kernel_for(t->nz, t->kind);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
