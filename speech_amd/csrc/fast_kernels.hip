@@ -47,7 +47,11 @@ namespace {
 
 constexpr int NT = 256;                 // threads per workgroup (4 waves)
 constexpr int QF = 4;                   // frames per wave (quad)
-constexpr int TILE = 16;                // frames per workgroup
+constexpr int TILE = 16;                // frames per workgroup, mel kinds
+constexpr int TILE_SPEC = 64;           // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
+constexpr int SUB = 16;                 // frames per sub-tile
+constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
+constexpr int TR_WAVE_C = 2048;         // floats of a wave's slice when the transposition image is complex (spectrogram kernel)
 constexpr int NFFT = 512, NC = 256, FB = 257;
 constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 8 * 16 * 2;
 constexpr int TR_WAVE = 1032;           // floats of a wave's LDS slice: 4 frames x 16 x 16 reals (transposition image of the real, then the
@@ -252,7 +256,7 @@ __device__ __forceinline__ void store_run(float *y, const float *s_src, int nout
 // On return lane k2 (= lane & 15) holds, for k1 = 0..7 (and k1 = 8, meaningful in lane k2 == 0 only):
 //   pa[k1] = 4 |X[k]|^2, pb[k1] = 4 |X[256 - k]|^2 with k = k2 + 16 k1 (the factor 4 is folded into what consumes them);
 //   rawe = the frame's (floored) energy.
-template <int NZ>
+template <int NZ, bool HALF>
 __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
                                             float (&pa)[9], float (&pb)[9], float &rawe)
 {
@@ -311,37 +315,58 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
     }
     rawe = fmaxf(row16_sum(e2.x + e2.y), FLT_EPSILON);
 
-    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through LDS, real parts then imaginary parts (a 1 KB
-    // image per frame keeps 7 workgroups on a CU): element (k2, n) lives at 16 k2 + 4 ((n>>2) ^ (k2>>2)) + (n&3), which
-    // makes the b32 writes and the b128 reads conflict-free
+    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through the wave's LDS slice
     fft16(z);
     const f2 *tw1 = reinterpret_cast<const f2 *>(s_tab + TAB_TW1);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) { z[P16(k2)] = cmul(z[P16(k2)], tw1[k2 * 16 + n1]); }
     wave_sync();                                                            // every lane has its samples: the slice becomes the transposition image
-    float *trf = s_tr + f * 256;
-    int woff[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
     const int k2 = n1;                                                      // the lane's role after the transpose
-    const float *rrow = trf + k2 * 16;
-    const int rq = k2 >> 2;
-    float4 rr[4];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].x; }
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { rr[q] = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2)); }
-    wave_sync();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].y; }
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
+    if (HALF)
     {
-        const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
-        const f2 r01 = {rr[q].x, rr[q].y}, r23 = {rr[q].z, rr[q].w}, i01 = {v.x, v.y}, i23 = {v.z, v.w};
-        z[4 * q] = pair_lo(r01, i01); z[4 * q + 1] = pair_hi(r01, i01); z[4 * q + 2] = pair_lo(r23, i23); z[4 * q + 3] = pair_hi(r23, i23);
+        // real parts then imaginary parts (a 1 KB image per frame keeps 7 workgroups on a CU): element (k2, n) lives at
+        // 16 k2 + 4 ((n>>2) ^ (k2>>2)) + (n&3), which makes the b32 writes and the b128 reads conflict-free
+        float *trf = s_tr + f * 256;
+        int woff[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
+        const float *rrow = trf + k2 * 16;
+        const int rq = k2 >> 2;
+        float4 rr[4];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].x; }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { rr[q] = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2)); }
+        wave_sync();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].y; }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
+            const f2 r01 = {rr[q].x, rr[q].y}, r23 = {rr[q].z, rr[q].w}, i01 = {v.x, v.y}, i23 = {v.z, v.w};
+            z[4 * q] = pair_lo(r01, i01); z[4 * q + 1] = pair_hi(r01, i01); z[4 * q + 2] = pair_lo(r23, i23); z[4 * q + 3] = pair_hi(r23, i23);
+        }
+    }
+    else
+    {
+        // complex image (2 KB per frame): element (k2, n) lives at float offset 32 k2 + 4 ((n>>1) ^ (k2>>1)) + 2 (n&1):
+        // b64 writes and b128 reads are both conflict-free and the pairs come back as pairs
+        float *trf = s_tr + f * 512;
+        const int wlo = 2 * (n1 & 1), wm = n1 >> 1;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { *reinterpret_cast<f2 *>(trf + 32 * kk + 4 * (wm ^ (kk >> 1)) + wlo) = z[P16(kk)]; }
+        wave_sync();
+        const float *rrow = trf + 32 * k2;
+        const int rg = k2 >> 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(rrow + 4 * (m ^ rg));
+            z[2 * m] = f2{v.x, v.y}; z[2 * m + 1] = f2{v.z, v.w};
+        }
     }
     wave_sync();
     fft16(z);                                                               // Z[k2 + 16 k1] at position P16(k1)
@@ -384,57 +409,117 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t ntiles)
     return x * q + (x < r ? x : r) + i;
 }
 
+// A zero the compiler cannot see through: added to the LDS table base inside the sub-tile loop so that the loop-invariant
+// table reads (window, twiddles: 74 registers' worth) are not hoisted out of the loop at the cost of occupancy.
+__device__ __forceinline__ int opaque_zero()
+{
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+
+// Geometry of the quad whose first frame is tile-relative frame fq: frames, first sample, samples needed.
+__device__ __forceinline__ int quad_geom(const FastParams &p, const TileDesc &tile, int fq, long long &s0, int &need)
+{
+    const int nfr = min((int)tile.nframes - fq, QF);
+    const long long w0 = (long long)tile.frame0 + fq;
+    s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));     // c/kaldi_mfcc.c:81-82
+    need = (nfr - 1) * p.stp + p.L;
+    return nfr;
+}
+
+// The next quad's audio is fetched into registers BEFORE the current quad's arithmetic and parked in the wave's LDS slice
+// after it, so the HBM latency of one quad hides behind the FFT of the previous one.  Interior quads only (an edge quad
+// of a snip_edges=0 utterance is loaded by load_span when its turn comes); loads past `need` return 0 (range check).
+struct Prefetch {
+    float v[NPRE];
+    bool on;
+};
+
+__device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p, const float *xu, long long s0, int need, long long N, int nfr, int lane)
+{
+    pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NPRE);
+    if (pf.on)
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) { pf.v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0)); }
+    }
+}
+
+__device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, const float *xu, long long s0, int need, long long N, int nfr, int lane)
+{
+    if (pf.on)
+    {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = pf.v[j]; }
+    }
+    else if (nfr > 0) { load_span(s_aud, xu, s0, need, N, lane); }
+}
+
 template <int NZ>
-__global__ __launch_bounds__(NT) void fast_spectrogram_kernel(const FastParams p)
+__global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
-    float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image, then output staging
+    float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
     for (int i = tid; i < TAB_FLOATS; i += NT) { s_tab[i] = p.tab[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
-    const int fq = wv * QF;                                                 // first frame of this wave's quad within the tile
-    const int nfr = min((int)tile.nframes - fq, QF);
-    if (nfr > 0)
-    {
-        const long long w0 = (long long)tile.frame0 + fq;
-        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
-        load_span(s_aud, p.X + utt.x_off, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
-    }
-    __syncthreads();                                                        // tables (and, wave-locally, the span) are in LDS
-    if (nfr <= 0) { return; }
+    const float *xu = p.X + utt.x_off;
+    const long long N = (long long)utt.n;
+    const int nsub = ((int)tile.nframes + SUB - 1) / SUB;
+    long long s0; int need;
+    int nfr = quad_geom(p, tile, wv * QF, s0, need);
+    if (nfr > 0) { load_span(s_aud, xu, s0, need, N, lane); }
+    __syncthreads();                                                        // tables (and, wave-locally, the first span) are in LDS
 
     const int f = lane >> 4, k2 = lane & 15;
-    float pa[9], pb[9], rawe;
-    frame_power<NZ>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
-
-    // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything.
-    // pa/pb carry 4 |X|^2: log(max(q/4, eps)) = ln2 * log2(max(q, 4 eps)) - 2 ln2.
-    // For each k1 the 16 lanes of a frame hold 16 consecutive bins: every store instruction writes four 64-byte runs, and
-    // consecutive instructions complete the 128-byte lines in L2.  The descriptor covers exactly the quad's nfr x 257
-    // outputs, so the rows of frames that do not exist are dropped by its range check.
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB), 0, nfr * FB * 4, BUF_FLAGS);
     const int oup = (f * FB + k2) * 4;                                      // bins k2 + 16 k1, ascending
     const int odn = (f * FB + NC - 112 - k2) * 4;                           // bins 256 - k2 - 16 k1, as 144 - k2 + 16 (7 - k1)
+    for (int it = 0; it < nsub; ++it)
     {
-        const float la = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
-        const float lb = spec_log(pb[0]);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, la), ry, oup, 0, 0);
-        if (k2 > 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64, 0); }
-        if (k2 == 1) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64 + 4, 0); }      // bin 256 := bin 255
-    }
+        const int fq = it * SUB + wv * QF;                                  // this wave's quad in sub-tile `it`
+        long long s0n; int needn;
+        const int nfrn = quad_geom(p, tile, fq + SUB, s0n, needn);
+        Prefetch pf;
+        prefetch_issue(pf, p, xu, s0n, needn, N, nfrn, lane);
+        if (nfr > 0)
+        {
+            float pa[9], pb[9], rawe;
+            frame_power<NZ, false>(s_aud + f * p.stp, s_tab + opaque_zero(), s_tr, lane, p, pa, pb, rawe);
+
+            // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything.
+            // pa/pb carry 4 |X|^2: log(max(q/4, eps)) = ln2 * log2(max(q, 4 eps)) - 2 ln2.
+            // For each k1 the 16 lanes of a frame hold 16 consecutive bins: every store instruction writes four 64-byte
+            // runs, and consecutive instructions complete the 128-byte lines in L2.  The descriptor covers exactly the
+            // quad's nfr x 257 outputs, so the rows of frames that do not exist are dropped by its range check.
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB), 0, nfr * FB * 4, BUF_FLAGS);
+            {
+                const float la = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
+                const float lb = spec_log(pb[0]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, la), ry, oup, 0, 0);
+                if (k2 > 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64, 0); }
+                if (k2 == 1) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64 + 4, 0); }      // bin 256 := bin 255
+            }
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1)
-    {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[k1])), ry, oup, 64 * k1, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pb[k1])), ry, odn, 64 * (7 - k1), 0);
+            for (int k1 = 1; k1 < 8; ++k1)
+            {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[k1])), ry, oup, 64 * k1, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pb[k1])), ry, odn, 64 * (7 - k1), 0);
+            }
+            if (k2 == 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[8])), ry, oup, 128 * 4, 0); }
+        }
+        wave_sync();                                                        // the transposition image has been read: the slice takes the next quad
+        prefetch_park(pf, s_aud, xu, s0n, needn, N, nfrn, lane);
+        wave_sync();
+        nfr = nfrn;
     }
-    if (k2 == 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[8])), ry, oup, 128 * 4, 0); }
 }
 
 // One 16 x 16 output tile of  A[16 frames][K] . Bm[K][16]  on the matrix cores.  `arow` points at this lane's A element
@@ -489,7 +574,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
 
     const int f = lane >> 4, k2 = lane & 15;
     float pa[9], pb[9], rawe = 1.0f;
-    if (nfr > 0) { frame_power<NZ>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe); }
+    if (nfr > 0) { frame_power<NZ, true>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe); }
     else
     {
 #pragma unroll
@@ -692,7 +777,7 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
     return (TAB_FLOATS + (NT / 64) * std::max(span, (size_t)TR_WAVE) + extra) * sizeof(float) <= 64u * 1024u;
 }
 
-int fast_tile_frames(const speech_opts &) { return TILE; }
+int fast_tile_frames(const speech_opts &o) { return o.kind == SPEECH_SPECTROGRAM ? TILE_SPEC : TILE; }
 
 static hipError_t upload_floats(const std::vector<float> &h, float **d)
 {
@@ -805,7 +890,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.X = fp.X; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     p.span = ((QF - 1) * fp.stp + 32 * t->nz + 3) & ~3;
-    p.ws = std::max(p.span, TR_WAVE);
+    p.ws = std::max(p.span, t->kind == SPEECH_SPECTROGRAM ? TR_WAVE_C : TR_WAVE);
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.tab = t->d_tab;
