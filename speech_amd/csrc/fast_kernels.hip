@@ -26,6 +26,7 @@
 #include <cfloat>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace speech {
@@ -68,6 +69,7 @@ struct FastParams {
     int L, stp, D, span, ws;            // span: floats of a quad's audio; ws: floats of a wave's LDS slice (>= span, TR_WAVE)
     int snip_edges, dc0, want_pre, want_post;
     float preemph;                      // 0 when pre-emphasis is off
+    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads (spectrogram kernel)
     const float *tab;
     // mel kinds
     const float *melw, *mat2, *aux;
@@ -224,7 +226,8 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, long lo
         const int nit = (need + 63) >> 6;
         for (int j = 0; j < nit; ++j)
         {
-            s_aud[lane + 64 * j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0));
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0));
+            if (lane + 64 * j < need) { s_aud[lane + 64 * j] = v; }         // the slice ends at `need` rounded up to 4, not to 64
         }
     }
     else
@@ -438,7 +441,7 @@ struct Prefetch {
 
 __device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p, const float *xu, long long s0, int need, long long N, int nfr, int lane)
 {
-    pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NPRE);
+    pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NPRE) && !(p.ablate & 2);
     if (pf.on)
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
@@ -447,14 +450,14 @@ __device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p
     }
 }
 
-__device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, const float *xu, long long s0, int need, long long N, int nfr, int lane)
+__device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, const float *xu, long long s0, int need, long long N, int nfr, int lane, int ablate)
 {
     if (pf.on)
     {
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = pf.v[j]; }
     }
-    else if (nfr > 0) { load_span(s_aud, xu, s0, need, N, lane); }
+    else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, s0, need, N, lane); }
 }
 
 template <int NZ>
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             // runs, and consecutive instructions complete the 128-byte lines in L2.  The descriptor covers exactly the
             // quad's nfr x 257 outputs, so the rows of frames that do not exist are dropped by its range check.
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB), 0, nfr * FB * 4, BUF_FLAGS);
+                (void *)(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB), 0, (p.ablate & 1) ? 0 : nfr * FB * 4, BUF_FLAGS);
             {
                 const float la = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
                 const float lb = spec_log(pb[0]);
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             if (k2 == 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[8])), ry, oup, 128 * 4, 0); }
         }
         wave_sync();                                                        // the transposition image has been read: the slice takes the next quad
-        prefetch_park(pf, s_aud, xu, s0n, needn, N, nfrn, lane);
+        prefetch_park(pf, s_aud, xu, s0n, needn, N, nfrn, lane, p.ablate);
         wave_sync();
         nfr = nfrn;
     }
@@ -893,6 +896,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.ws = std::max(p.span, t->kind == SPEECH_SPECTROGRAM ? TR_WAVE_C : TR_WAVE);
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
+    { const char *ab = getenv("SPEECH_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }     // timing diagnostics, DESIGN.md 4.3
     p.tab = t->d_tab;
     p.melw = t->d_melw; p.mat2 = t->d_mat2; p.aux = t->d_aux;
     p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;

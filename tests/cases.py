@@ -71,6 +71,19 @@ _add("spectrogram", 3000, 606, sr=16000.0, fl=32.0, fs=16.0)     # L=512 == nfft
 _add("fbank", 30000, 607, sr=48000.0, fl=100.0, fs=40.0, hif=24000.0, B=80)   # L=4800 -> nfft 8192 (generic kernel)
 _add("mfcc", 900, 608, sr=16000.0, fl=1.0, fs=0.5, B=6, C=4, hif=8000.0)      # L=16 -> nfft 16 (generic kernel)
 
+# every zero-padding variant of the tuned 512-point kernels (NZ = ceil(L/32) = 9..16), odd L, and frame shifts from
+# heavy overlap to gaps between frames; long enough for several 64-frame tiles with reflected edges
+for i, fl in enumerate((17.0, 20.0, 22.0, 24.0, 26.0, 28.0, 30.0, 32.0)):
+    _add(("spectrogram", "fbank", "mfcc", "plp")[i % 4], 9000, 800 + i, fl=fl, snip=i % 2)
+_add("spectrogram", 9000, 810, sr=16040.0)                       # L=401 (odd), stp=160
+_add("mfcc", 9000, 811, fs=5.0, snip=0)                          # stp=80
+_add("fbank", 9000, 812, fs=12.5, B=40)                          # stp=200
+_add("spectrogram", 20000, 813, fl=20.0, fs=30.0, snip=0)        # stp=480 > L=320: gaps between frames
+_add("plp", 9000, 814, fs=20.0)                                  # stp=320
+_add("mfcc", 9000, 815, sr=16100.0, fs=10.0)                     # stp=161 (odd): generic kernel
+for i, kind in enumerate(("spectrogram", "fbank", "mfcc", "plp")):
+    _add(kind, 20333, 820 + i, snip=0, use_energy=i % 2) if kind != "spectrogram" else _add(kind, 20333, 820 + i, snip=0)
+
 # mean normalisation (intended D-wide form; reference-pinned only where D == B)
 _add("fbank", 2500, 700, mn0=1)
 _add("mfcc", 2500, 701, B=40, C=40, mn0=1)
