@@ -1,0 +1,278 @@
+// cli/kaldi_cli.cpp -- drop-in command-line tools kaldi_spectrogram, kaldi_fbank, kaldi_mfcc, kaldi_plp.
+//
+// Same flags, defaults, validation messages and exit codes as the reference's generated CLIs (srci/kaldi_mfcc.cpp:84-172
+// and src/kaldi_mfcc.cpp:118-327; fbank srci/kaldi_fbank.cpp:89-106; spectrogram src/kaldi_spectrogram.cpp; plp
+// srci/kaldi_plp.cpp:84-101), but linked against libspeech.so (include/codee_speech.h) instead of unity-including the
+// .c file.  One source, built four times with -DTOOL=<n> (cli/Makefile).
+//
+// Differences, both forced by what is absent here: argtable2 is replaced by getopt_long (same short and long names), and
+// the tensor header of the reference's sibling repo (util/cmli.hpp, not in the tree) is replaced by the public .npy
+// format: the input is a 1-D (or 1xN / Nx1) '<f4' or '<f8' .npy, the output a 2-D .npy of the same dtype, W x D for a
+// C-order input and D x W (fortran_order) for a Fortran-order input -- "samples from one frame are contiguous in memory"
+// either way (src/kaldi_mfcc.cpp:78-81, :259-260).  kaldi_fbank accepts float only, as the reference (srci/kaldi_fbank.cpp:6).
+#include <cctype>
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <getopt.h>
+#include <iostream>
+#include <string>
+#include <unistd.h>
+#include <vector>
+#include "../include/codee_speech.h"
+
+#define TOOL_SPECTROGRAM 0
+#define TOOL_FBANK 1
+#define TOOL_MFCC 2
+#define TOOL_PLP 3
+#ifndef TOOL
+#define TOOL TOOL_MFCC
+#endif
+
+using namespace std;
+
+static const char *prog()
+{
+    return TOOL == TOOL_SPECTROGRAM ? "kaldi_spectrogram" : TOOL == TOOL_FBANK ? "kaldi_fbank" : TOOL == TOOL_MFCC ? "kaldi_mfcc" : "kaldi_plp";
+}
+
+static int fail(int line, const string &msg)
+{
+    cerr << prog() << ": " << line << ": \033[1;31merror:\033[0m " << msg << endl;       // src/kaldi_mfcc.cpp:32
+    return 1;
+}
+#define FAIL(msg) return fail(__LINE__, msg)
+
+struct NpyInfo { bool f64 = false, fortran = false; vector<size_t> shape; size_t n = 0; };
+
+// .npy v1/v2/v3 header (public format): magic, version, little-endian header length, python dict literal
+static bool read_npy_header(istream &is, NpyInfo &h)
+{
+    char magic[8];
+    if (!is.read(magic, 8) || memcmp(magic, "\x93NUMPY", 6) != 0) { return false; }
+    size_t hlen = 0;
+    if (magic[6] == 1) { unsigned char b[2]; if (!is.read((char *)b, 2)) { return false; } hlen = b[0] | (b[1] << 8); }
+    else { unsigned char b[4]; if (!is.read((char *)b, 4)) { return false; } hlen = b[0] | (b[1] << 8) | (b[2] << 16) | ((size_t)b[3] << 24); }
+    if (hlen > (1u << 20)) { return false; }
+    string d(hlen, '\0');
+    if (!is.read(&d[0], (streamsize)hlen)) { return false; }
+    const size_t pd = d.find("'descr'"), pf = d.find("'fortran_order'"), ps = d.find("'shape'");
+    if (pd == string::npos || pf == string::npos || ps == string::npos) { return false; }
+    const size_t q1 = d.find('\'', d.find(':', pd)), q2 = d.find('\'', q1 + 1);
+    if (q1 == string::npos || q2 == string::npos) { return false; }
+    const string descr = d.substr(q1 + 1, q2 - q1 - 1);
+    if (descr == "<f4" || descr == "|f4" || descr == "=f4") { h.f64 = false; }
+    else if (descr == "<f8" || descr == "|f8" || descr == "=f8") { h.f64 = true; }
+    else { return false; }
+    h.fortran = d.compare(d.find_first_not_of(" ", d.find(':', pf) + 1), 4, "True") == 0;
+    const size_t p1 = d.find('(', ps), p2 = d.find(')', p1);
+    if (p1 == string::npos || p2 == string::npos) { return false; }
+    h.shape.clear(); h.n = 1;
+    const string sh = d.substr(p1 + 1, p2 - p1 - 1);
+    size_t i = 0;
+    while (i < sh.size())
+    {
+        while (i < sh.size() && !isdigit((unsigned char)sh[i])) { ++i; }
+        if (i >= sh.size()) { break; }
+        size_t v = 0;
+        while (i < sh.size() && isdigit((unsigned char)sh[i])) { v = v * 10 + (size_t)(sh[i] - '0'); ++i; }
+        h.shape.push_back(v); h.n *= v;
+    }
+    return true;
+}
+
+static bool write_npy_header(ostream &os, bool f64, bool fortran, size_t r, size_t c)
+{
+    string d = string("{'descr': '") + (f64 ? "<f8" : "<f4") + "', 'fortran_order': " + (fortran ? "True" : "False") + ", 'shape': (" + to_string(r) + ", " + to_string(c) + "), }";
+    while ((10 + d.size() + 1) % 64 != 0) { d += ' '; }
+    d += '\n';
+    const unsigned char pre[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char)(d.size() & 0xFF), (unsigned char)(d.size() >> 8)};
+    os.write((const char *)pre, 10); os.write(d.data(), (streamsize)d.size());
+    return (bool)os;
+}
+
+static void usage()
+{
+    cout << "Usage: " << prog() << " [<file>] [-r <dbl>] [-t <dbl>] [-s <dbl>] [-e] [-d <dbl>] [-z] [-y] [-p <dbl>] [-w <str>]";
+    if (TOOL == TOOL_FBANK) { cout << " [-a] [-l <dbl>] [-u <dbl>] [-b <uint>] [-g] [-x]"; }
+    if (TOOL == TOOL_MFCC || TOOL == TOOL_PLP) { cout << " [-l <dbl>] [-u <dbl>] [-b <uint>] [-c <uint>] [-q <dbl>] [-x]"; }
+    if (TOOL == TOOL_PLP) { cout << " [--compress=<dbl>] [--cep_scale=<dbl>]"; }
+    cout << " [-m] [-o <file>] [-h]\n\n";
+    const char *fmt = "  %-25s %s\n";
+    printf(fmt, "<file>", "input file (X), .npy float32/float64 vector; stdin if absent or -");
+    printf(fmt, "-r, --srate=<dbl>", "sample rate in Hz [default=16000.0]");
+    printf(fmt, "-t, --frame_length=<dbl>", "length in ms of each frame [default=25]");
+    printf(fmt, "-s, --frame_shift=<dbl>", "step in ms between each frame [default=10]");
+    printf(fmt, "-e, --snip_edges", "include to snip edges [default=false]");
+    printf(fmt, "-d, --dither=<dbl>", "dither weight [default=0.1]");
+    printf(fmt, "-z, --zero_dc", "include to zero the mean of each frame [default=false]");
+    printf(fmt, "-y, --raw_energy", "include to compute energy before preemph [default=false]");
+    printf(fmt, "-p, --preemph=<dbl>", "preemphasis coefficient in [0 1] [default=0.97]");
+    printf(fmt, "-w, --wintype=<str>", "window type [default='povey']");
+    if (TOOL == TOOL_FBANK) { printf(fmt, "-a, --amp", "include to use amplitude (sqrt of power) [default=false]"); }
+    if (TOOL != TOOL_SPECTROGRAM)
+    {
+        printf(fmt, "-l, --lof=<dbl>", "mel-bank low-freq in Hz [default=20.0]");
+        printf(fmt, "-u, --hif=<dbl>", "mel-bank high-freq in Hz [default=Nyquist]; <= 0 is an offset from Nyquist");
+        printf(fmt, "-b, --B=<uint>", "number of mel bins [default=23]");
+    }
+    if (TOOL == TOOL_FBANK) { printf(fmt, "-g, --log", "include to output log of amplitude or power [default=false]"); }
+    if (TOOL == TOOL_MFCC || TOOL == TOOL_PLP)
+    {
+        printf(fmt, "-c, --C=<uint>", "number of cepstral coeffs [default=13]");
+        printf(fmt, "-q, --Q=<dbl>", "lifter coeff [default=22.0]");
+    }
+    if (TOOL == TOOL_PLP)
+    {
+        printf(fmt, "--compress=<dbl>", "compression exponent [default=0.33333]");
+        printf(fmt, "--cep_scale=<dbl>", "cepstral scale [default=1.0]");
+    }
+    if (TOOL != TOOL_SPECTROGRAM) { printf(fmt, "-x, --use_energy", "include to use raw energy as (first / extra) feat [default=false]"); }
+    printf(fmt, "-m, --zero_mean", "include to zero the means of each feat in Y [default=false]");
+    printf(fmt, "-o, --ofile=<file>", "output file (Y), .npy; stdout if - or piped");
+    printf(fmt, "-h, --help", "display this help and exit");
+    cout << "\nMakes Kaldi " << (TOOL == TOOL_SPECTROGRAM ? "spectrogram" : TOOL == TOOL_FBANK ? "mel-fbank" : TOOL == TOOL_MFCC ? "MFCC" : "PLP")
+         << " features for univariate, real-valued X on an AMD MI355X (libspeech.so).\n"
+         << "The number of output frames (W) is set as in Kaldi:\n"
+         << "If snip_edges=true:  W = 1u + (N-L)/stp   \nIf snip_edges=false: W = (N+stp/2u) / stp \n"
+         << "Samples from one frame are contiguous in memory: Y is W x D for a C-order input, D x W for a Fortran-order input.\n"
+         << "Use -d0 to turn off dithering (the default 0.1 adds seeded Gaussian noise).\n\n"
+         << "Examples:\n$ " << prog() << " -e -z -d0 X.npy -o Y.npy \n$ cat X.npy | " << prog() << " -e -z - > Y.npy \n";
+}
+
+int main(int argc, char *argv[])
+{
+    double sr = 16000.0, fl = 25.0, shft = 10.0, d = 0.1, p = 0.97, lof = 20.0, hif = 0.0, Q = 22.0, compress = 1.0 / 3.0, cep_scale = 1.0;
+    long Bi = 23, Ci = 13;
+    int snipe = 0, dc0 = 0, rawe = 0, amp = 0, lg = 0, usee = 0, mn0 = 0, help = 0;
+    string wintype = "povey", ofile;
+    bool have_o = false;
+
+    static const option longopts[] = {
+        {"srate", required_argument, nullptr, 'r'}, {"frame_length", required_argument, nullptr, 't'}, {"frame_shift", required_argument, nullptr, 's'},
+        {"snip_edges", no_argument, nullptr, 'e'}, {"dither", required_argument, nullptr, 'd'}, {"zero_dc", no_argument, nullptr, 'z'},
+        {"raw_energy", no_argument, nullptr, 'y'}, {"preemph", required_argument, nullptr, 'p'}, {"wintype", required_argument, nullptr, 'w'},
+        {"amp", no_argument, nullptr, 'a'}, {"lof", required_argument, nullptr, 'l'}, {"hif", required_argument, nullptr, 'u'},
+        {"B", required_argument, nullptr, 'b'}, {"log", no_argument, nullptr, 'g'}, {"C", required_argument, nullptr, 'c'}, {"Q", required_argument, nullptr, 'q'},
+        {"use_energy", no_argument, nullptr, 'x'}, {"zero_mean", no_argument, nullptr, 'm'}, {"ofile", required_argument, nullptr, 'o'},
+        {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001}, {nullptr, 0, nullptr, 0}};
+    const char *shortopts = TOOL == TOOL_SPECTROGRAM ? "r:t:s:ed:zyp:w:mo:h" : TOOL == TOOL_FBANK ? "r:t:s:ed:zyp:w:al:u:b:gxmo:h" : "r:t:s:ed:zyp:w:l:u:b:c:q:xmo:h";
+    int c, nerrs = 0;
+    opterr = 0;
+    while ((c = getopt_long(argc, argv, shortopts, longopts, nullptr)) != -1)
+    {
+        char *end = nullptr;
+        auto num = [&](double &v) { v = strtod(optarg, &end); if (end == optarg || *end) { ++nerrs; cerr << prog() << ": invalid argument \"" << optarg << "\" to option" << endl; } };
+        switch (c)
+        {
+            case 'r': num(sr); break; case 't': num(fl); break; case 's': num(shft); break; case 'e': snipe = 1; break;
+            case 'd': num(d); break; case 'z': dc0 = 1; break; case 'y': rawe = 1; break; case 'p': num(p); break;
+            case 'w': wintype = optarg; break; case 'a': amp = 1; break; case 'l': num(lof); break; case 'u': num(hif); break;
+            case 'b': Bi = strtol(optarg, &end, 10); if (end == optarg || *end) { ++nerrs; } break;
+            case 'g': lg = 1; break;
+            case 'c': Ci = strtol(optarg, &end, 10); if (end == optarg || *end) { ++nerrs; } break;
+            case 'q': num(Q); break; case 'x': usee = 1; break; case 'm': mn0 = 1; break;
+            case 'o': ofile = optarg; have_o = true; break; case 'h': help = 1; break;
+            case 1000: if (TOOL == TOOL_PLP) { num(compress); } else { ++nerrs; } break;
+            case 1001: if (TOOL == TOOL_PLP) { num(cep_scale); } else { ++nerrs; } break;
+            default: ++nerrs; cerr << prog() << ": invalid option \"" << argv[optind - 1] << "\"" << endl; break;
+        }
+    }
+    if (help) { usage(); return 1; }                                                        // src/kaldi_mfcc.cpp:142-147: help exits with 1
+    if (nerrs > 0) { FAIL("invalid command line; try -h"); }
+    if (argc - optind > 1) { FAIL("too many input files"); }
+    const string ifile = (optind < argc) ? argv[optind] : "";
+
+    // stdin / stdout detection: src/kaldi_mfcc.cpp:151-159
+    const bool stdi1 = ifile.empty() || ifile == "-";
+    if (stdi1 && isatty(fileno(stdin))) { FAIL("no stdin detected"); }
+    const bool stdo1 = have_o ? (ofile.empty() || ofile == "-") : !isatty(fileno(stdout));
+    const bool wo1 = stdo1 || have_o;
+
+    ifstream ifs1;
+    if (!stdi1) { ifs1.open(ifile, ios::binary); if (!ifs1) { FAIL("problem opening input file"); } }
+    istream &is = stdi1 ? cin : ifs1;
+    NpyInfo i1;
+    if (!read_npy_header(is, i1)) { FAIL("problem reading header for input file"); }
+    if (TOOL == TOOL_FBANK && i1.f64) { FAIL("input data type must be in {1}"); }            // srci/kaldi_fbank.cpp:6
+
+    // options: src/kaldi_mfcc.cpp:179-246
+    if (sr < DBL_EPSILON) { FAIL("srate (sample rate) must be nonnegative"); }
+    if (fl < DBL_EPSILON) { FAIL("frame length must be positive"); }
+    if (shft < DBL_EPSILON) { FAIL("frame shift must be positive"); }
+    if (d < 0.0) { FAIL("d must be nonnegative"); }
+    if (p < 0.0 || p > 1.0) { FAIL("p must be in [0.0 1.0]"); }
+    for (auto &ch : wintype) { ch = (char)tolower((unsigned char)ch); }
+    size_t B = 23, C = 13;
+    if (TOOL != TOOL_SPECTROGRAM)
+    {
+        if (lof < 0.0) { FAIL("lof must be nonnegative"); }
+        if (hif < DBL_EPSILON) { hif = 0.5 * sr + hif; }                                     // offset from Nyquist
+        if (hif <= lof) { FAIL("hif must be > lof"); }
+        if (Bi < 1) { FAIL("B must be positive"); }
+        B = (size_t)Bi;
+    }
+    if (TOOL == TOOL_MFCC || TOOL == TOOL_PLP)
+    {
+        if (Ci < 1) { FAIL("C must be positive"); }
+        C = (size_t)Ci;
+        if (C > B) { FAIL("C (num ceps) must be <= B (num fbank bins)"); }
+        if (Q < 0.0) { FAIL("Q must be nonnegative"); }
+    }
+
+    // checks: src/kaldi_mfcc.cpp:250-251
+    size_t big = 0;
+    for (size_t s : i1.shape) { if (s > 1) { ++big; } }
+    if (big > 1) { FAIL("input (X) must be a vector"); }
+    const size_t N = i1.shape.empty() ? 1 : i1.n;
+    if (N == 0) { FAIL("input (X) found to be empty"); }
+
+    // output shape: src/kaldi_mfcc.cpp:255-261 (sizes in double here, in the working precision inside the library)
+    const size_t L = (size_t)(sr * fl / 1000.0), stp = (size_t)(sr * shft / 1000.0);
+    if (stp < 1 || (snipe && L > N)) { FAIL("frame length must be < signal length if snip_edges, and frame shift at least one sample"); }
+    const size_t W = snipe ? 1u + (N - L) / stp : (N + stp / 2u) / stp;
+    size_t nfft = 1; while (nfft < L) { nfft *= 2; }
+    const size_t D = TOOL == TOOL_SPECTROGRAM ? nfft / 2 + 1 : TOOL == TOOL_FBANK ? B + (usee ? 1u : 0u) : C;
+
+    ofstream ofs1;
+    if (wo1 && !stdo1) { ofs1.open(ofile, ios::binary); if (!ofs1) { FAIL("problem opening output file 1"); } }
+    ostream &os = stdo1 ? cout : ofs1;
+    if (wo1 && !write_npy_header(os, i1.f64, i1.fortran, i1.fortran ? D : W, i1.fortran ? W : D)) { FAIL("problem writing header for output file 1"); }
+
+    timespec tic, toc;
+    clock_gettime(CLOCK_REALTIME, &tic);
+    int rc;
+    if (!i1.f64)
+    {
+        vector<float> X(N), Y(W * D + 1);
+        if (!is.read((char *)X.data(), (streamsize)(N * sizeof(float)))) { FAIL("problem reading input file (X)"); }
+        if (TOOL == TOOL_SPECTROGRAM) { rc = codee::kaldi_spectrogram_s(Y.data(), X.data(), N, (float)sr, (float)fl, (float)shft, snipe, (float)d, dc0, rawe, (float)p, wintype.c_str(), mn0); }
+        else if (TOOL == TOOL_FBANK) { rc = codee::kaldi_fbank_s(Y.data(), X.data(), N, (float)sr, (float)fl, (float)shft, snipe, (float)d, dc0, rawe, (float)p, wintype.c_str(), amp, (float)lof, (float)hif, B, lg, usee, mn0); }
+        else if (TOOL == TOOL_MFCC) { rc = codee::kaldi_mfcc_s(Y.data(), X.data(), N, (float)sr, (float)fl, (float)shft, snipe, (float)d, dc0, rawe, (float)p, wintype.c_str(), (float)lof, (float)hif, B, C, (float)Q, usee, mn0); }
+        else { rc = codee::kaldi_plp_s(Y.data(), X.data(), N, (float)sr, (float)fl, (float)shft, snipe, (float)d, dc0, rawe, (float)p, wintype.c_str(), (float)lof, (float)hif, B, (float)compress, C, (float)Q, (float)cep_scale, usee, mn0); }
+        if (rc) { FAIL("problem during function call"); }
+        if (wo1 && !os.write((const char *)Y.data(), (streamsize)(W * D * sizeof(float)))) { FAIL("problem writing output file (Y)"); }
+    }
+    else
+    {
+        vector<double> X(N), Y(W * D + 1);
+        if (!is.read((char *)X.data(), (streamsize)(N * sizeof(double)))) { FAIL("problem reading input file (X)"); }
+        if (TOOL == TOOL_SPECTROGRAM) { rc = codee::kaldi_spectrogram_d(Y.data(), X.data(), N, sr, fl, shft, snipe, d, dc0, rawe, p, wintype.c_str(), mn0); }
+        else if (TOOL == TOOL_FBANK) { rc = codee::kaldi_fbank_d(Y.data(), X.data(), N, sr, fl, shft, snipe, d, dc0, rawe, p, wintype.c_str(), amp, lof, hif, B, lg, usee, mn0); }
+        else if (TOOL == TOOL_MFCC) { rc = codee::kaldi_mfcc_d(Y.data(), X.data(), N, sr, fl, shft, snipe, d, dc0, rawe, p, wintype.c_str(), lof, hif, B, C, Q, usee, mn0); }
+        else { rc = codee::kaldi_plp_d(Y.data(), X.data(), N, sr, fl, shft, snipe, d, dc0, rawe, p, wintype.c_str(), lof, hif, B, compress, C, Q, cep_scale, usee, mn0); }
+        if (rc) { FAIL("problem during function call"); }
+        if (wo1 && !os.write((const char *)Y.data(), (streamsize)(W * D * sizeof(double)))) { FAIL("problem writing output file (Y)"); }
+    }
+    os.flush();
+    clock_gettime(CLOCK_REALTIME, &toc);
+    if (TOOL != TOOL_SPECTROGRAM)                                                            // generated with -t: src/kaldi_mfcc.cpp:321-322; the spectrogram tool is not (Makefile:47)
+    {
+        cerr << "elapsed time = " << double(toc.tv_sec - tic.tv_sec) * 1e3 + double(toc.tv_nsec - tic.tv_nsec) / 1e6 << " ms" << endl;
+    }
+    return 0;
+}

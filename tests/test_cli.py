@@ -1,0 +1,102 @@
+"""Drop-in CLIs (cli/kaldi_cli.cpp): flags, defaults, exit codes and messages of the reference tools
+(src/kaldi_mfcc.cpp:118-327, srci/kaldi_fbank.cpp:89-106), .npy in and out."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import signals
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "cli", "bin")
+TOOLS = ["kaldi_spectrogram", "kaldi_fbank", "kaldi_mfcc", "kaldi_plp"]
+
+
+def run(tool, *args, stdin=None):
+    return subprocess.run([os.path.join(BIN, tool), *args], input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not all(os.path.exists(os.path.join(BIN, t)) for t in TOOLS):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cli")])
+
+
+@pytest.mark.parametrize("tool", TOOLS)
+def test_help_prints_usage_and_exits_1(tool):
+    r = run(tool, "-h")
+    assert r.returncode == 1                                    # src/kaldi_mfcc.cpp:142-147
+    out = r.stdout.decode()
+    assert out.startswith("Usage: " + tool)
+    for flag in ("--srate", "--frame_length", "--frame_shift", "--snip_edges", "--dither", "--zero_dc", "--raw_energy", "--preemph",
+                 "--wintype", "--zero_mean", "--ofile"):
+        assert flag in out
+    assert ("--B=" in out) == (tool != "kaldi_spectrogram")
+    assert ("--C=" in out) == (tool in ("kaldi_mfcc", "kaldi_plp"))
+    assert ("--amp" in out) == (tool == "kaldi_fbank")
+
+
+def test_validation_messages_and_codes(tmp_path):
+    x = tmp_path / "x.npy"
+    np.save(x, np.zeros(4000, np.float32))
+    for args, msg in [(("-c", "30"), "C (num ceps) must be <= B (num fbank bins)"), (("-p", "1.5"), "p must be in [0.0 1.0]"),
+                      (("-d", "-1"), "d must be nonnegative"), (("-l", "9000"), "hif must be > lof"), (("-b", "0"), "B must be positive"),
+                      (("-t", "0"), "frame length must be positive")]:
+        r = run("kaldi_mfcc", *args, str(x), "-o", str(tmp_path / "y.npy"))
+        assert r.returncode == 1 and msg in r.stderr.decode(), (args, r.stderr)
+    r = run("kaldi_mfcc", str(tmp_path / "missing.npy"), "-o", str(tmp_path / "y.npy"))
+    assert r.returncode == 1 and "problem opening input file" in r.stderr.decode()
+    bad = tmp_path / "bad.npy"
+    bad.write_bytes(b"not a tensor")
+    r = run("kaldi_mfcc", str(bad), "-o", str(tmp_path / "y.npy"))
+    assert r.returncode == 1 and "problem reading header for input file" in r.stderr.decode()
+    m = tmp_path / "m.npy"
+    np.save(m, np.zeros((4, 5), np.float32))
+    r = run("kaldi_mfcc", str(m), "-o", str(tmp_path / "y.npy"))
+    assert r.returncode == 1 and "input (X) must be a vector" in r.stderr.decode()
+    d = tmp_path / "d.npy"
+    np.save(d, np.zeros(4000, np.float64))
+    r = run("kaldi_fbank", str(d), "-o", str(tmp_path / "y.npy"))
+    assert r.returncode == 1 and "input data type must be in {1}" in r.stderr.decode()     # srci/kaldi_fbank.cpp:6
+    r = run("kaldi_spectrogram", "-b", "40", str(x), "-o", str(tmp_path / "y.npy"))         # not a spectrogram flag
+    assert r.returncode == 1
+
+
+@pytest.mark.gpu
+def test_cli_matches_library(tmp_path):
+    from speech_amd import api
+    x = signals.utterance(8000, 42)
+    xf = tmp_path / "x.npy"
+    np.save(xf, x)
+    # kaldi_mfcc -e -z -y -d0: Kaldi-style front end
+    r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "-b40", "-c20", str(xf), "-o", str(tmp_path / "y.npy"))
+    assert r.returncode == 0, r.stderr
+    assert b"elapsed time = " in r.stderr                       # src/kaldi_mfcc.cpp:321-322
+    y = np.load(tmp_path / "y.npy")
+    assert np.array_equal(y, api.kaldi_mfcc(x, B=40, C=20))
+    # CLI defaults: snip_edges, zero_dc, raw_energy all off; hif = Nyquist; fbank linear unless -g
+    r = run("kaldi_fbank", "-d0", "-g", "-u", "-400", "-x", str(xf), "-o", str(tmp_path / "f.npy"))
+    assert r.returncode == 0, r.stderr
+    f = np.load(tmp_path / "f.npy")
+    assert np.array_equal(f, api.kaldi_fbank(x, snip_edges=0, dc0=0, raw_energy=0, hif=7600.0, lg=1, use_energy=1))
+    # stdin -> stdout, spectrogram (no timing line: generated without -t in the reference, Makefile:47)
+    r = run("kaldi_spectrogram", "-e", "-z", "-d0", "-", stdin=xf.read_bytes())
+    assert r.returncode == 0 and b"elapsed" not in r.stderr
+    import io
+    s = np.load(io.BytesIO(r.stdout))
+    assert np.array_equal(s, api.kaldi_spectrogram(x, raw_energy=0))
+    # float64 input and Fortran order: D x W, frames contiguous
+    xd = tmp_path / "xd.npy"
+    with open(xd, "wb") as fh:                                  # numpy itself never writes fortran_order for a vector: build the header by hand
+        np.lib.format.write_array_header_1_0(fh, {"descr": "<f8", "fortran_order": True, "shape": (x.size, 1)})
+        fh.write(x.astype(np.float64).tobytes())
+    r = run("kaldi_plp", "-e", "-z", "-y", "-d0", str(xd), "-o", str(tmp_path / "p.npy"))
+    assert r.returncode == 0, r.stderr
+    pl = np.load(tmp_path / "p.npy")
+    ref = api.kaldi_plp(x.astype(np.float64))
+    assert pl.dtype == np.float64 and pl.shape == ref.shape[::-1] and np.isfortran(pl) and np.array_equal(pl.T, ref)
+    # default dither 0.1 is on and seeded: runs, differs from -d0, reproducible
+    a = run("kaldi_mfcc", "-e", str(xf), "-o", str(tmp_path / "a.npy")); b = run("kaldi_mfcc", "-e", str(xf), "-o", str(tmp_path / "b.npy"))
+    assert a.returncode == 0 and b.returncode == 0
+    assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))
