@@ -133,6 +133,38 @@ def cpu_baseline(work, budget_s=10.0):
                       % (passes, n, tot_secs, work.name, tot_dt)}
 
 
+def config0_single_utterance():
+    """BASELINE.json configs[0]: kaldi_mfcc on ONE 10 s utterance through the drop-in symbol (host pointers, synchronous:
+    H2D + kernel + D2H per call), beside the same call of the CPU oracle on one host thread."""
+    from speech_amd import api
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    rng = np.random.default_rng(7)
+    x = (1000.0 * rng.standard_normal(160000)).astype(np.float32)
+    api.kaldi_mfcc(x)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        api.kaldi_mfcc(x)
+    gpu_ms = (time.perf_counter() - t0) / 50 * 1e3
+    lib = O.lib("liboracle_native.so")
+    lib.oracle_set_fft_exact(0)
+    pz, pf = C.POINTER(C.c_size_t), C.POINTER(C.c_float)
+    y = np.zeros(998 * 13, dtype=np.float32)
+    zero, n = np.zeros(1, dtype=np.uint64), np.array([x.size], dtype=np.uint64)
+
+    def cpu_call():
+        assert lib.oracle_batch_s(2, 1, x.ctypes.data_as(pf), zero.ctypes.data_as(pz), n.ctypes.data_as(pz), y.ctypes.data_as(pf), zero.ctypes.data_as(pz),
+                                  SR, 25.0, 10.0, 1, 1, 1, 0.97, b"povey", 0, 20.0, 8000.0, 23, 1, 13, 22.0, 1.0 / 3.0, 1.0, 0, 1) >= 1
+    cpu_call()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        cpu_call()
+    cpu_ms = (time.perf_counter() - t0) / 20 * 1e3
+    return {"workload": "kaldi_mfcc_s, one 10 s utterance, 23 mel / 13 ceps, host pointers in and out",
+            "hip_ms_per_call": gpu_ms, "hip_audio_s_per_s": 10.0 / (gpu_ms * 1e-3),
+            "cpu_oracle_ms_per_call_1_thread": cpu_ms, "cpu_audio_s_per_s": 10.0 / (cpu_ms * 1e-3)}
+
+
 def pcie_inclusive(work, device, nutt=64):
     """Host buffers in, host buffers out (what the drop-in kaldi_*_s symbols do per call), batched: H2D + kernels + D2H."""
     import torch
@@ -223,6 +255,7 @@ def main():
         if not args.no_extras and world == 1:       # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(work)
             out["pcie_inclusive_audio_s_per_s"] = pcie_inclusive(work, device)
+            out["config0_single_utterance"] = config0_single_utterance()
     if not args.no_extras and world == 1 and args.workload == HEADLINE:
         others = {}
         work.free()

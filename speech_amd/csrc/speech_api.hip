@@ -579,6 +579,64 @@ int speech_batch_run_timed(speech_batch *b, const void *X, void *Y, void *stream
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// The reference rebuilds its tables on every call (c/kaldi_mfcc.c:105-210).  Here a call looks its option set up in a
+// small process-wide cache of plans (plans are immutable once built, so threads share them) and stages through
+// per-thread device buffers that only grow, so that repeated calls cost two copies and one launch.
+struct PlanCacheEntry { speech_opts o; int device; speech_plan *plan; unsigned long long stamp; };
+std::mutex g_cache_mu;
+std::vector<PlanCacheEntry> g_cache;
+unsigned long long g_cache_clock = 0;
+constexpr size_t PLAN_CACHE_MAX = 16;
+
+bool same_opts(const speech_opts &a, const speech_opts &b)
+{
+    return a.kind == b.kind && a.dtype == b.dtype && a.sr == b.sr && a.frame_length == b.frame_length && a.frame_shift == b.frame_shift &&
+           a.snip_edges == b.snip_edges && a.dither == b.dither && a.dc0 == b.dc0 && a.raw_energy == b.raw_energy && a.preemph == b.preemph &&
+           strncmp(a.win_type, b.win_type, sizeof(a.win_type)) == 0 && a.amp == b.amp && a.lof == b.lof && a.hif == b.hif && a.B == b.B &&
+           a.lg == b.lg && a.use_energy == b.use_energy && a.C == b.C && a.Q == b.Q && a.compress == b.compress && a.cep_scale == b.cep_scale &&
+           a.lpc_order == b.lpc_order && a.mn0 == b.mn0 && a.dither_seed == b.dither_seed && a.force_generic == b.force_generic;
+}
+
+speech_plan *cached_plan(const speech_opts &o, int dev)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto &e : g_cache) { if (e.device == dev && same_opts(e.o, o)) { e.stamp = ++g_cache_clock; return e.plan; } }
+    speech_plan *p = nullptr;
+    if (speech_plan_create(&p, &o, dev)) { return nullptr; }
+    if (g_cache.size() >= PLAN_CACHE_MAX)
+    {
+        // The least recently used plan is dropped from the table but not destroyed: another thread may be running it.
+        // At most one plan per distinct option set ever used is kept alive, a few KB of tables each.
+        size_t lru = 0;
+        for (size_t i = 1; i < g_cache.size(); ++i) { if (g_cache[i].stamp < g_cache[lru].stamp) { lru = i; } }
+        g_cache.erase(g_cache.begin() + (long)lru);
+    }
+    g_cache.push_back(PlanCacheEntry{o, dev, p, ++g_cache_clock});
+    return p;
+}
+
+struct StageBuffers { void *dX = nullptr, *dY = nullptr; size_t capX = 0, capY = 0; int device = -1; };
+
+int stage_reserve(const char *fn, StageBuffers &sb, int dev, size_t bytesX, size_t bytesY)
+{
+    if (sb.device != dev) { sb = StageBuffers(); sb.device = dev; }          // buffers of another device stay with that device
+    if (bytesX > sb.capX)
+    {
+        if (sb.dX) { (void)hipFree(sb.dX); sb.dX = nullptr; sb.capX = 0; }
+        const size_t cap = bytesX + bytesX / 4;
+        if (hipMalloc(&sb.dX, cap) != hipSuccess) { return fail(fn, "problem with hipMalloc"); }
+        sb.capX = cap;
+    }
+    if (bytesY > sb.capY)
+    {
+        if (sb.dY) { (void)hipFree(sb.dY); sb.dY = nullptr; sb.capY = 0; }
+        const size_t cap = bytesY + bytesY / 4;
+        if (hipMalloc(&sb.dY, cap) != hipSuccess) { return fail(fn, "problem with hipMalloc"); }
+        sb.capY = cap;
+    }
+    return 0;
+}
+
 template <typename T>
 int legacy_call(speech_opts &o, T *Y, const T *X, size_t N)
 {
@@ -589,30 +647,27 @@ int legacy_call(speech_opts &o, T *Y, const T *X, size_t N)
     if (o.snip_edges && sz.L > N) { return fail(fn, "frame length must be < signal length if snip_edges"); }   // c/kaldi_mfcc.c:70
     if (N > 2147483647u) { return fail(fn, "N above 2^31-1 is not supported (int-indexed, c/kaldi_mfcc.c:82-84)"); }
     const size_t W = o.snip_edges ? 1u + (N - sz.L) / sz.stp : (N + sz.stp / 2u) / sz.stp;     // c/kaldi_mfcc.c:77
-    if (W == 0u) { return 0; }                                                                 // c/kaldi_mfcc.c:78
+    if (W == 0u) { return 0; }                                                                 // c/kaldi_mfcc.c:78 (before the window name is looked at)
+    if (!window_known(o.win_type)) { return fail(fn, "window type must be rectangular, blackman, hamming, hann or povey (lower-cased)"); }
     if (!X || !Y) { return fail(fn, "null pointer"); }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { return fail(fn, "no HIP device available (this library has no CPU fallback)"); }
-    speech_plan *p = nullptr; speech_batch *b = nullptr;
-    if (speech_plan_create(&p, &o, dev)) { return 1; }
-    int rc = 1;
-    void *dX = nullptr, *dY = nullptr;
+    speech_plan *p = cached_plan(o, dev);
+    if (!p) { return 1; }
+    static thread_local StageBuffers sb;
     const size_t nout = W * sz.D;
+    if (stage_reserve(fn, sb, dev, N * sizeof(T), nout * sizeof(T))) { return 1; }
+    speech_batch *b = nullptr;
+    int rc = 1;
     do
     {
         if (speech_batch_create(&b, p, 1u, &N, nullptr, nullptr)) { break; }
-        if (hipMalloc(&dX, N * sizeof(T)) != hipSuccess || hipMalloc(&dY, nout * sizeof(T)) != hipSuccess) { fail(fn, "problem with hipMalloc"); break; }
-        if (hipMemcpy(dX, X, N * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { fail(fn, "problem copying X to the device"); break; }
-        if (speech_batch_run(b, dX, dY, nullptr)) { break; }
-        hipError_t e = hipStreamSynchronize(nullptr);
-        if (e != hipSuccess) { fail(fn, "kernel execution failed: %s", hipGetErrorString(e)); break; }
-        if (hipMemcpy(Y, dY, nout * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) { fail(fn, "problem copying Y from the device"); break; }
+        if (hipMemcpy(sb.dX, X, N * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { fail(fn, "problem copying X to the device"); break; }
+        if (speech_batch_run(b, sb.dX, sb.dY, nullptr)) { break; }
+        if (hipMemcpy(Y, sb.dY, nout * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) { fail(fn, "kernel execution or copy of Y failed"); break; }
         rc = 0;
     } while (0);
-    if (dX) { (void)hipFree(dX); }
-    if (dY) { (void)hipFree(dY); }
     if (b) { speech_batch_destroy(b); }
-    speech_plan_destroy(p);
     return rc;
 }
 
