@@ -1,0 +1,37 @@
+// Micro-benchmark: the memory traffic of the headline spectrogram workload with no arithmetic -- each 256-thread
+// workgroup reads 64 frames' worth of audio (10,240 floats) and writes 64 x 257 floats, dword per lane as the kernel does.
+// Gives the memory-only floor for this read:write mix (0.64 GB : 1.03 GB per launch).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+__global__ __launch_bounds__(256) void rw(const float *x, float *y, int in_per_wg, int out_per_wg, int mode)
+{
+    const float *xi = x + (size_t)blockIdx.x * in_per_wg;
+    float *yo = y + (size_t)blockIdx.x * out_per_wg;
+    float acc = 0.0f;
+    if (mode & 1) { for (int i = threadIdx.x; i < in_per_wg; i += 256) { acc += xi[i]; } }
+    if (mode & 2) { for (int i = threadIdx.x; i < out_per_wg; i += 256) { yo[i] = acc + (float)i; } }
+    else if (acc == 12345.678f) { yo[threadIdx.x] = acc; }
+}
+int main()
+{
+    const int nwg = 15625, in_per_wg = 10240, out_per_wg = 64 * 257;
+    float *x, *y;
+    CHECK(hipMalloc(&x, (size_t)nwg * in_per_wg * 4)); CHECK(hipMalloc(&y, (size_t)nwg * out_per_wg * 4));
+    CHECK(hipMemset(x, 0, (size_t)nwg * in_per_wg * 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int mode = 1; mode <= 3; ++mode)
+    {
+        float best = 1e9f;
+        for (int rep = 0; rep < 10; ++rep)
+        {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(rw, dim3(nwg), dim3(256), 0, 0, x, y, in_per_wg, out_per_wg, mode);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) { best = ms; }
+        }
+        const double bytes = ((mode & 1) ? (double)nwg * in_per_wg * 4 : 0.0) + ((mode & 2) ? (double)nwg * out_per_wg * 4 : 0.0);
+        printf("%s: %.3f ms, %.2f TB/s\n", mode == 1 ? "read 0.64 GB" : mode == 2 ? "write 1.03 GB" : "read 0.64 GB + write 1.03 GB", best, bytes / (best * 1e-3) / 1e12);
+    }
+    return 0;
+}
