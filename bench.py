@@ -205,14 +205,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    device = torch.device("cuda", local_rank)
+    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- lets the N>1 code path be exercised on a one-GPU box
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if rehearsal:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     work = Work(args.workload, device, rank)
@@ -226,7 +235,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -279,7 +288,7 @@ def main():
             torch.cuda.empty_cache()
         out["other_workloads_1gpu"] = others
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
