@@ -69,7 +69,7 @@ struct FastParams {
     int L, stp, D, span, ws;            // span: floats of a quad's audio, rounded up to 64; ws: floats of a wave's LDS slice (>= span, TR_WAVE)
     int snip_edges, dc0, want_pre, want_post;
     float preemph;                      // 0 when pre-emphasis is off
-    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads (spectrogram kernel)
+    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads (spectrogram kernel), 4 = mel kinds stop after the FFT
     const float *tab;
     // mel kinds
     const float *melw, *mat2, *aux;
@@ -545,6 +545,32 @@ __device__ __forceinline__ f32x4 mfma_tile(const float *arow, const float *brow,
     return acc0 + acc1;
 }
 
+// The mel contraction: `ksteps` is a multiple of 4 (host pads with zero weights).  Operands of the next four k-steps are
+// loaded while the current four MFMAs run, so the L1/L2 latency of the weights is paid once per tile instead of per step
+// (8 more VGPRs; fetching deeper costs occupancy and measured slower).
+__device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const float *brow, const int ksteps)
+{
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ksteps <= 0) { return acc0; }
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b[j] = brow[64 * j]; a[j] = arow[4 * j]; }
+    for (int s = 0; s < ksteps; s += 4)
+    {
+        const int sn = min(s + 4, ksteps - 4);                              // the last trip reloads its own block (harmless)
+        float an[4], bn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bn[j] = brow[64 * (sn + j)]; an[j] = arow[4 * (sn + j)]; }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = an[j]; b[j] = bn[j]; }
+    }
+    return acc0 + acc1;
+}
+
 // fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
 // Levinson-Durbin and the cepstral recursion stay in registers).
 template <int NZ, int KIND, int P>
@@ -585,6 +611,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
         for (int i = 0; i < 9; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
     }
     __syncthreads();                                                        // every wave is done with its slice
+    if (p.ablate & 4) { if (pa[0] + pb[3] + rawe == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> 16 x 257 tile, column 257 zero
     {
@@ -610,7 +637,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     const int fr0 = (lane >> 4) * 4, col = lane & 15;
     for (int t = wv; t < p.ntile_m; t += NT / 64)
     {
-        const f32x4 acc = mfma_tile(s_pow + col * PP + p.mel_kbeg[t] + (lane >> 4), p.melw + p.mel_woff[t] + lane, 64, p.mel_ksteps[t]);
+        const f32x4 acc = mfma_tile4(s_pow + col * PP + p.mel_kbeg[t] + (lane >> 4), p.melw + p.mel_woff[t] + lane, p.mel_ksteps[t]);
         const int m = 16 * t + col;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -834,7 +861,8 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, s
                 if (src[c] >= 0 && num[src[c]] > 0) { kmin = std::min(kmin, beg[src[c]]); kmax = std::max(kmax, beg[src[c]] + num[src[c]]); }
             }
             int ks = 0, kb = 0;
-            if (kmax > kmin) { ks = (kmax - kmin + 3) / 4; kb = kmin; if (kb + 4 * ks > PP) { kb = PP - 4 * ks; } }
+            // k-steps in whole groups of four (mfma_tile4); the extra bins carry zero weights and stay inside the 258-column tile
+            if (kmax > kmin) { ks = (((kmax - kmin + 3) / 4) + 3) & ~3; kb = kmin; if (kb + 4 * ks > PP) { kb = PP - 4 * ks; } }
             if (kb < 0) { delete t; return nullptr; }                       // a tile spanning more than 256 bins: generic kernels
             t->mel_kbeg[tl] = kb; t->mel_ksteps[tl] = ks; t->mel_woff[tl] = (int)melw.size();
             melw.resize(melw.size() + (size_t)64 * ks, 0.0f);
