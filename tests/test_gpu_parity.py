@@ -233,3 +233,17 @@ def test_dither_is_seeded_and_has_the_right_scale():
     assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
     # bin 0 is log of the frame energy of pure unit-variance noise: E = 400 on average
     assert abs(np.exp(outs[0][:, 0]).mean() - 400.0) < 20.0
+
+
+def test_which_plans_run_on_the_tuned_kernels():
+    """every BASELINE.json configuration is served by the tuned gfx950 kernels; option sets outside their envelope fall
+    back to the generic kernels instead of failing"""
+    tuned = [("mfcc", {}), ("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {}),
+             ("fbank", dict(fl=20.0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("fbank", dict(B=23, hif=9000.0))]
+    generic = [("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("spectrogram", dict(sr=22050.0)), ("mfcc", dict(sr=16100.0)),
+               ("plp", dict(order=16)), ("fbank", dict(B=120)), ("mfcc", dict(dither=0.5)), ("fbank", dict(B=1))]
+    for kind, o in tuned:
+        assert api.Plan(kind, **o).tuned, (kind, o)
+    for kind, o in generic:
+        assert not api.Plan(kind, **o).tuned, (kind, o)
+    assert not api.Plan("mfcc", dtype="f64").tuned
