@@ -32,6 +32,8 @@ WORKLOADS = {
     "fbank80_ragged_1-30s": dict(kind="fbank", opts=dict(B=80, lg=1, lof=20.0, hif=8000.0, **FRONT), lens="ragged", nutt=2000),
     "mfcc13_1000x10s": dict(kind="mfcc", opts=dict(B=23, C=13, Q=22.0, lof=20.0, hif=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
     "mfcc_hires40_1000x10s": dict(kind="mfcc", opts=dict(B=40, C=40, Q=22.0, lof=20.0, hif=7600.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
+    # widening: the same spectrogram batch fed as 16-bit PCM (speech_batch_run_pcm16), 2 N + 4 W D bytes
+    "spectrogram_pcm16_1000x10s": dict(kind="spectrogram", opts=dict(**FRONT), lens="fixed", nutt=1000, secs=10.0, pcm16=True),
     "plp13_1000x10s": dict(kind="plp", opts=dict(B=23, C=13, Q=22.0, compress=1.0 / 3.0, cep_scale=1.0, lof=20.0, hif=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
 }
 HEADLINE = "spectrogram_1000x10s"
@@ -71,10 +73,13 @@ class Work:
         self.lens = lengths(w, rank)
         self.batch = api.Batch(self.plan, self.lens)
         self.X = synth_audio(self.batch.total_samples, device, 1234 + rank)
+        self.pcm16 = bool(w.get("pcm16"))
+        if self.pcm16:
+            self.X = self.X.round().clamp(-32767, 32767).to(torch.int16)
         self.Y = torch.zeros(self.batch.total_out, device=device, dtype=torch.float32)
         self.audio_s = float(self.batch.total_samples) / SR
         # algorithmic bytes per launch: read every sample once, write every feature once
-        self.bytes = 4.0 * self.batch.total_samples + 4.0 * self.batch.total_out
+        self.bytes = (2.0 if self.pcm16 else 4.0) * self.batch.total_samples + 4.0 * self.batch.total_out
 
     def step(self, stream):
         self.batch.run(self.X, self.Y, stream=stream)

@@ -81,6 +81,12 @@ int speech_batch_run(speech_batch *batch, const void *X_dev, void *Y_dev, void *
    completion and returns that kernel's duration in milliseconds. */
 int speech_batch_run_timed(speech_batch *batch, const void *X_dev, void *Y_dev, void *stream, float *kernel_ms);
 
+/* Widening (no counterpart in the reference, whose tools take float tensors only, srci/kaldi_mfcc.cpp:6):
+   the same batch with the audio as 16-bit PCM on the device (same element offsets).  Samples are converted to the plan's
+   dtype as they are loaded (exact), so the features equal speech_batch_run on the converted audio bit for bit, for half the
+   input bytes over PCIe and HBM.  kernel_ms may be NULL (asynchronous) or receives the per-frame kernel's duration. */
+int speech_batch_run_pcm16(speech_batch *batch, const short *X16_dev, void *Y_dev, void *stream, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

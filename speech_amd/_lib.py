@@ -21,7 +21,7 @@ EXT_SYMBOLS = [
     "speech_opts_default", "speech_device_count", "speech_last_error",
     "speech_plan_create", "speech_plan_destroy", "speech_plan_sizes", "speech_plan_num_frames",
     "speech_batch_create", "speech_batch_destroy", "speech_batch_totals", "speech_batch_offsets",
-    "speech_batch_run", "speech_batch_run_timed",
+    "speech_batch_run", "speech_batch_run_timed", "speech_batch_run_pcm16",
 ]
 
 
@@ -85,6 +85,7 @@ def load():
     lib.speech_batch_offsets.argtypes = [vp, pz, pz, pz]; lib.speech_batch_offsets.restype = i
     lib.speech_batch_run.argtypes = [vp, vp, vp, vp]; lib.speech_batch_run.restype = i
     lib.speech_batch_run_timed.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]; lib.speech_batch_run_timed.restype = i
+    lib.speech_batch_run_pcm16.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]; lib.speech_batch_run_pcm16.restype = i
     _lib = lib
     return lib
 

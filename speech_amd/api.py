@@ -168,9 +168,16 @@ class Batch:
         self.n_samples = n
 
     def run(self, X, Y, stream=None, timed=False):
-        """X, Y: torch tensors on the plan's device (1-D, plan dtype).  stream: a raw hipStream_t value
+        """X, Y: torch tensors on the plan's device (1-D, plan dtype; X may also be int16 PCM).  stream: a raw hipStream_t value
         (e.g. torch.cuda.current_stream().cuda_stream) or None for the default stream."""
         sp = C.c_void_p(stream) if stream else None
+        if str(X.dtype).endswith("int16"):
+            # 16-bit PCM on the device (speech_batch_run_pcm16): converted to the plan's dtype as it is loaded
+            ms = C.c_float()
+            rc = self._lib.speech_batch_run_pcm16(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()), sp, C.byref(ms) if timed else None)
+            if rc != 0:
+                raise SpeechError(_lib.last_error())
+            return ms.value if timed else None
         if timed:
             ms = C.c_float()
             rc = self._lib.speech_batch_run_timed(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()), sp, C.byref(ms))

@@ -62,6 +62,7 @@ constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descript
 
 struct FastParams {
     const float *X;
+    const short *X16;                   // non-null: the audio is 16-bit PCM (speech_batch_run_pcm16), converted on the way into LDS
     float *Y;
     const UttDesc *utts;
     const TileDesc *tiles;
@@ -215,20 +216,26 @@ __device__ __forceinline__ float spec_log(float q)
 }
 
 // Load the wave's audio slice: `need` samples starting at utterance-relative position s0 (may be negative or run past N
-// when snip_edges is off: reflected as c/kaldi_mfcc.c:228).  All arguments but `lane` are wave-uniform.
-// Interior quads use raw buffer loads: 256 B per wave-instruction, lane offset in one VGPR, the step in an SGPR, and
-// the descriptor's range check instead of a per-lane bound test.
-__device__ __forceinline__ void load_span(float *s_aud, const float *xu, long long s0, int need, long long N, int lane)
+// when snip_edges is off: reflected as c/kaldi_mfcc.c:228).  All arguments but `lane` are wave-uniform.  xu16 non-null:
+// the utterance is 16-bit PCM at xu16 and is converted here (exact), otherwise float at xu.
+// Interior quads use raw buffer loads: one sample per lane per instruction, lane offset in one VGPR, the step in an
+// SGPR, and the descriptor's range check instead of a per-lane bound test.
+__device__ __forceinline__ void load_span(float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int lane)
 {
     if (s0 >= 0 && s0 + need <= N)
     {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
         const int nit = (need + 63) >> 6;
-        for (int j = 0; j < nit; ++j)
+        // no per-lane bound: the slice is a whole number of 64-float rows (a guarded store here serialises the loads:
+        // 0.78 vs 0.57 ms on the mfcc workload), loads past `need` return 0
+        if (xu16)
         {
-            // no per-lane bound: the slice is a whole number of 64-float rows (a guarded store here serialises the loads:
-            // 0.78 vs 0.57 ms on the mfcc workload), loads past `need` return 0
-            s_aud[lane + 64 * j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu16 + s0), 0, need * 2, BUF_FLAGS);
+            for (int j = 0; j < nit; ++j) { s_aud[lane + 64 * j] = (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, j * 128, 0); }
+        }
+        else
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
+            for (int j = 0; j < nit; ++j) { s_aud[lane + 64 * j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0)); }
         }
     }
     else
@@ -237,7 +244,7 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, long lo
         {
             long long n = s0 + i;
             while (n < 0 || n >= N) { n = (n < 0) ? -n - 1 : 2 * N - 1 - n; }
-            s_aud[i] = xu[n];
+            s_aud[i] = xu16 ? (float)xu16[n] : xu[n];
         }
     }
 }
@@ -436,14 +443,21 @@ __device__ __forceinline__ int quad_geom(const FastParams &p, const TileDesc &ti
 // after it, so the HBM latency of one quad hides behind the FFT of the previous one.  Interior quads only (an edge quad
 // of a snip_edges=0 utterance is loaded by load_span when its turn comes); loads past `need` return 0 (range check).
 struct Prefetch {
-    float v[NPRE];
-    bool on;
+    float v[NPRE];                      // float samples, or the raw 16-bit PCM words (converted when parked)
+    bool on, pcm;
 };
 
-__device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p, const float *xu, long long s0, int need, long long N, int nfr, int lane)
+__device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane)
 {
     pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NPRE) && !(p.ablate & 2);
-    if (pf.on)
+    pf.pcm = (xu16 != nullptr);
+    if (pf.on && pf.pcm)
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu16 + s0), 0, need * 2, BUF_FLAGS);
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) { pf.v[j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, j * 128, 0)); }
+    }
+    else if (pf.on)
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
 #pragma unroll
@@ -451,14 +465,19 @@ __device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p
     }
 }
 
-__device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, const float *xu, long long s0, int need, long long N, int nfr, int lane, int ablate)
+__device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane, int ablate)
 {
-    if (pf.on)
+    if (pf.on && pf.pcm)
+    {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = (float)(short)(unsigned short)__builtin_bit_cast(unsigned, pf.v[j]); }
+    }
+    else if (pf.on)
     {
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = pf.v[j]; }
     }
-    else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, s0, need, N, lane); }
+    else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
 }
 
 template <int NZ>
@@ -475,11 +494,12 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
     const float *xu = p.X + utt.x_off;
+    const short *xu16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
     const int nsub = ((int)tile.nframes + SUB - 1) / SUB;
     long long s0; int need;
     int nfr = quad_geom(p, tile, wv * QF, s0, need);
-    if (nfr > 0) { load_span(s_aud, xu, s0, need, N, lane); }
+    if (nfr > 0) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
     __syncthreads();                                                        // tables (and, wave-locally, the first span) are in LDS
 
     const int f = lane >> 4, k2 = lane & 15;
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         long long s0n; int needn;
         const int nfrn = quad_geom(p, tile, fq + SUB, s0n, needn);
         Prefetch pf;
-        prefetch_issue(pf, p, xu, s0n, needn, N, nfrn, lane);
+        prefetch_issue(pf, p, xu, xu16, s0n, needn, N, nfrn, lane);
         if (nfr > 0)
         {
             float pa[9], pb[9], rawe;
@@ -520,7 +540,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             if (k2 == 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[8])), ry, oup, 128 * 4, 0); }
         }
         wave_sync();                                                        // the transposition image has been read: the slice takes the next quad
-        prefetch_park(pf, s_aud, xu, s0n, needn, N, nfrn, lane, p.ablate);
+        prefetch_park(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
         wave_sync();
         nfr = nfrn;
     }
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     {
         const long long w0 = (long long)tile.frame0 + fq;
         const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
-        load_span(s_aud, p.X + utt.x_off, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
+        load_span(s_aud, p.X + utt.x_off, p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
     }
     __syncthreads();
 
@@ -919,7 +939,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     if (fp.ntiles == 0) { return hipSuccess; }
     FastParams p;
     memset(&p, 0, sizeof(p));
-    p.X = fp.X; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
+    p.X = fp.X; p.X16 = fp.X16; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     p.span = ((QF - 1) * fp.stp + 32 * t->nz + 63) & ~63;     // whole 64-lane load instructions fit the slice
     p.ws = std::max(p.span, t->kind == SPEECH_SPECTROGRAM ? TR_WAVE_C : TR_WAVE);

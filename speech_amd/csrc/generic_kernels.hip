@@ -82,6 +82,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
     const TileDesc tile = p.tiles[blockIdx.x];
     const UttDesc utt = p.utts[tile.utt];
     const T *x = p.X + utt.x_off;
+    const short *x16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
     const T eps = (T)FLT_EPSILON;
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
             {
                 long long n = start + l;
                 while (n < 0 || n >= N) { n = (n < 0) ? -n - 1 : 2 * N - 1 - n; }   // reflect: c/kaldi_mfcc.c:228
-                v = x[n];
+                v = x16 ? (T)x16[n] : x[n];
             }
             re[l] = v;
         }

@@ -311,12 +311,12 @@ int plan_build<float>(speech_plan *p)
 }
 
 template <typename T>
-void fill_params(const speech_batch *b, const void *X, void *Y, FrameParams<T> *fp)
+void fill_params(const speech_batch *b, const void *X, const short *X16, void *Y, FrameParams<T> *fp)
 {
     const speech_plan *p = b->plan;
     const speech_opts &o = p->o;
     memset(fp, 0, sizeof(*fp));
-    fp->X = (const T *)X; fp->Y = (T *)Y;
+    fp->X = (const T *)X; fp->X16 = X16; fp->Y = (T *)Y;
     fp->utts = b->d_utts; fp->tiles = b->d_tiles; fp->ntiles = (uint32_t)b->tiles.size();
     fp->kind = o.kind;
     fp->L = (int)p->sz.L; fp->stp = (int)p->sz.stp; fp->nfft = (int)p->sz.nfft; fp->F = (int)p->sz.F; fp->log2n = p->sz.log2n;
@@ -343,13 +343,13 @@ void fill_params(const speech_batch *b, const void *X, void *Y, FrameParams<T> *
     fp->mel_out = nullptr;
 }
 
-int batch_run(speech_batch *b, const void *X, void *Y, void *stream, float *kernel_ms)
+int batch_run(speech_batch *b, const void *X, const short *X16, void *Y, void *stream, float *kernel_ms)
 {
     const char *fn = "speech_batch_run";
     if (!b || !b->plan) { return fail(fn, "null batch"); }
     speech_plan *p = b->plan;
     if (b->tiles.empty()) { if (kernel_ms) { *kernel_ms = 0.0f; } return 0; }
-    if (!X || !Y) { return fail(fn, "null device pointer"); }
+    if ((!X && !X16) || !Y) { return fail(fn, "null device pointer"); }
     DeviceGuard g(p->device);
     if (!g.ok) { return fail(fn, "cannot select device %d", p->device); }
     hipStream_t s = (hipStream_t)stream;
@@ -361,14 +361,14 @@ int batch_run(speech_batch *b, const void *X, void *Y, void *stream, float *kern
     }
     if (p->o.dtype == SPEECH_F64)
     {
-        FrameParams<double> fp; fill_params<double>(b, X, Y, &fp);
+        FrameParams<double> fp; fill_params<double>(b, X, X16, Y, &fp);
         if (e0) { HIP_TRY(fn, hipEventRecord(e0, s)); }
         HIP_TRY(fn, launch_generic_f64(fp, s));
         if (e1) { HIP_TRY(fn, hipEventRecord(e1, s)); }
     }
     else
     {
-        FrameParams<float> fp; fill_params<float>(b, X, Y, &fp);
+        FrameParams<float> fp; fill_params<float>(b, X, X16, Y, &fp);
         if (p->tuned) { HIP_TRY(fn, launch_fast(p->fast, fp, b->d_scratch, s, e0, e1)); }
         else
         {
@@ -564,12 +564,18 @@ int speech_batch_offsets(const speech_batch *b, size_t *x_off, size_t *y_off, si
     return 0;
 }
 
-int speech_batch_run(speech_batch *b, const void *X, void *Y, void *stream) { return batch_run(b, X, Y, stream, nullptr); }
+int speech_batch_run(speech_batch *b, const void *X, void *Y, void *stream) { return batch_run(b, X, nullptr, Y, stream, nullptr); }
+
+int speech_batch_run_pcm16(speech_batch *b, const short *X16, void *Y, void *stream, float *kernel_ms)
+{
+    if (!X16) { return fail("speech_batch_run_pcm16", "null device pointer"); }
+    return batch_run(b, nullptr, X16, Y, stream, kernel_ms);
+}
 
 int speech_batch_run_timed(speech_batch *b, const void *X, void *Y, void *stream, float *kernel_ms)
 {
     if (!kernel_ms) { return fail("speech_batch_run_timed", "null kernel_ms"); }
-    return batch_run(b, X, Y, stream, kernel_ms);
+    return batch_run(b, X, nullptr, Y, stream, kernel_ms);
 }
 
 }  // extern "C"

@@ -29,6 +29,7 @@ struct TileDesc {
 template <typename T>
 struct FrameParams {
     const T *X;
+    const short *X16;            // non-null: 16-bit PCM input (same element offsets), X is then unused
     T *Y;
     const UttDesc *utts;
     const TileDesc *tiles;

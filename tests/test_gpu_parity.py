@@ -247,3 +247,34 @@ def test_which_plans_run_on_the_tuned_kernels():
     for kind, o in generic:
         assert not api.Plan(kind, **o).tuned, (kind, o)
     assert not api.Plan("mfcc", dtype="f64").tuned
+
+
+@pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(snip=0)), ("plp", {}),
+                                    ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("fbank", dict(B=40, snip=0, force_generic=1))])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_pcm16_input_equals_float_input(kind, o, dtype):
+    """speech_batch_run_pcm16: int16 audio converted on load gives bit-identical features to the float path on the same
+    (integer-valued) audio, over a ragged batch with reflected edges; and so matches the oracle"""
+    import torch
+    if dtype == "f64" and o.get("force_generic"):
+        pytest.skip("f64 is always generic")
+    lens = [16000, 400, 4799, 40000, 561]
+    xs = [signals.utterance(n, 1200 + i, sr=o.get("sr", 16000.0)) for i, n in enumerate(lens)]
+    x = np.concatenate(xs)
+    assert np.array_equal(x, np.round(x)) and np.abs(x).max() <= 32767
+    td = torch.float32 if dtype == "f32" else torch.float64
+    plan = api.Plan(kind, dtype=dtype, **o)
+    b = api.Batch(plan, lens)
+    Xf = torch.from_numpy(x).to(td).cuda()
+    Xi = torch.from_numpy(x.astype(np.int16)).cuda()
+    Yf = torch.zeros(b.total_out, device="cuda", dtype=td)
+    Yi = torch.full((b.total_out,), float("nan"), device="cuda", dtype=td)
+    b.run(Xf, Yf)
+    b.run(Xi, Yi)
+    torch.cuda.synchronize()
+    assert torch.equal(Yf, Yi)
+    if dtype == "f32":
+        got = Yi.cpu().numpy()[:int(b.n_frames[0]) * plan.D].reshape(-1, plan.D)
+        oo = {k: v for k, v in o.items() if k != "force_generic"}
+        ok, msg = _parity(kind, oo, xs[0], got)
+        assert ok, msg
