@@ -10,6 +10,11 @@
 // format: the input is a 1-D (or 1xN / Nx1) '<f4' or '<f8' .npy, the output a 2-D .npy of the same dtype, W x D for a
 // C-order input and D x W (fortran_order) for a Fortran-order input -- "samples from one frame are contiguous in memory"
 // either way (src/kaldi_mfcc.cpp:78-81, :259-260).  kaldi_fbank accepts float only, as the reference (srci/kaldi_fbank.cpp:6).
+//
+// Widening: --ark=<utt-id> writes the features as one entry of a Kaldi binary archive instead of a .npy
+// ("<utt-id> \0B" "FM " \4 <int32 rows> \4 <int32 cols> <rows x cols floats>, "DM " for double -- the layout the
+// reference's kaldi2bin scans for, src/kaldi2bin.cpp:141-175), --append adds it to an existing archive, and
+// --scp=<file> appends the matching "<utt-id> <ark>:<offset>" line, so the tools can stand in for compute-mfcc-feats.
 #include <cctype>
 #include <cfloat>
 #include <cstdint>
@@ -134,6 +139,9 @@ static void usage()
     if (TOOL != TOOL_SPECTROGRAM) { printf(fmt, "-x, --use_energy", "include to use raw energy as (first / extra) feat [default=false]"); }
     printf(fmt, "-m, --zero_mean", "include to zero the means of each feat in Y [default=false]");
     printf(fmt, "-o, --ofile=<file>", "output file (Y), .npy; stdout if - or piped");
+    printf(fmt, "--ark=<utt-id>", "write Y as a Kaldi binary archive entry with this key instead of .npy");
+    printf(fmt, "--append", "with --ark: append to the archive instead of replacing it");
+    printf(fmt, "--scp=<file>", "with --ark and -o: append \"<utt-id> <ofile>:<offset>\" to this script file");
     printf(fmt, "-h, --help", "display this help and exit");
     cout << "\nMakes Kaldi " << (TOOL == TOOL_SPECTROGRAM ? "spectrogram" : TOOL == TOOL_FBANK ? "mel-fbank" : TOOL == TOOL_MFCC ? "MFCC" : "PLP")
          << " features for univariate, real-valued X on an AMD MI355X (libspeech.so).\n"
@@ -149,8 +157,8 @@ int main(int argc, char *argv[])
     double sr = 16000.0, fl = 25.0, shft = 10.0, d = 0.1, p = 0.97, lof = 20.0, hif = 0.0, Q = 22.0, compress = 1.0 / 3.0, cep_scale = 1.0;
     long Bi = 23, Ci = 13;
     int snipe = 0, dc0 = 0, rawe = 0, amp = 0, lg = 0, usee = 0, mn0 = 0, help = 0;
-    string wintype = "povey", ofile;
-    bool have_o = false;
+    string wintype = "povey", ofile, ark_key, scp_file;
+    bool have_o = false, append = false;
 
     static const option longopts[] = {
         {"srate", required_argument, nullptr, 'r'}, {"frame_length", required_argument, nullptr, 't'}, {"frame_shift", required_argument, nullptr, 's'},
@@ -159,7 +167,8 @@ int main(int argc, char *argv[])
         {"amp", no_argument, nullptr, 'a'}, {"lof", required_argument, nullptr, 'l'}, {"hif", required_argument, nullptr, 'u'},
         {"B", required_argument, nullptr, 'b'}, {"log", no_argument, nullptr, 'g'}, {"C", required_argument, nullptr, 'c'}, {"Q", required_argument, nullptr, 'q'},
         {"use_energy", no_argument, nullptr, 'x'}, {"zero_mean", no_argument, nullptr, 'm'}, {"ofile", required_argument, nullptr, 'o'},
-        {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001}, {nullptr, 0, nullptr, 0}};
+        {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001},
+        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {nullptr, 0, nullptr, 0}};
     const char *shortopts = TOOL == TOOL_SPECTROGRAM ? "r:t:s:ed:zyp:w:mo:h" : TOOL == TOOL_FBANK ? "r:t:s:ed:zyp:w:al:u:b:gxmo:h" : "r:t:s:ed:zyp:w:l:u:b:c:q:xmo:h";
     int c, nerrs = 0;
     opterr = 0;
@@ -179,6 +188,9 @@ int main(int argc, char *argv[])
             case 'o': ofile = optarg; have_o = true; break; case 'h': help = 1; break;
             case 1000: if (TOOL == TOOL_PLP) { num(compress); } else { ++nerrs; } break;
             case 1001: if (TOOL == TOOL_PLP) { num(cep_scale); } else { ++nerrs; } break;
+            case 1002: ark_key = optarg; break;
+            case 1003: scp_file = optarg; break;
+            case 1004: append = true; break;
             default: ++nerrs; cerr << prog() << ": invalid option \"" << argv[optind - 1] << "\"" << endl; break;
         }
     }
@@ -238,10 +250,30 @@ int main(int argc, char *argv[])
     size_t nfft = 1; while (nfft < L) { nfft *= 2; }
     const size_t D = TOOL == TOOL_SPECTROGRAM ? nfft / 2 + 1 : TOOL == TOOL_FBANK ? B + (usee ? 1u : 0u) : C;
 
+    const bool ark = !ark_key.empty();
+    if (ark && (ark_key.find_first_of(" \t\n") != string::npos)) { FAIL("ark utterance id must not contain white space"); }
+    if (!ark && (append || !scp_file.empty())) { FAIL("--append and --scp need --ark=<utt-id>"); }
+    if (!scp_file.empty() && (stdo1 || !wo1)) { FAIL("--scp needs an output file (-o), not stdout"); }
     ofstream ofs1;
-    if (wo1 && !stdo1) { ofs1.open(ofile, ios::binary); if (!ofs1) { FAIL("problem opening output file 1"); } }
+    long long ark_off = 0;
+    if (wo1 && !stdo1)
+    {
+        ofs1.open(ofile, (ark && append) ? (ios::binary | ios::app) : (ios::binary | ios::trunc));
+        if (!ofs1) { FAIL("problem opening output file 1"); }
+        if (ark && append) { ofs1.seekp(0, ios::end); ark_off = (long long)ofs1.tellp(); }
+    }
     ostream &os = stdo1 ? cout : ofs1;
-    if (wo1 && !write_npy_header(os, i1.f64, i1.fortran, i1.fortran ? D : W, i1.fortran ? W : D)) { FAIL("problem writing header for output file 1"); }
+    if (wo1 && ark)
+    {
+        // Kaldi binary matrix entry, always frame-major (W x D)
+        const int32_t rows = (int32_t)W, cols = (int32_t)D;
+        os << ark_key << ' ';
+        ark_off += (long long)ark_key.size() + 1;                                            // the scp offset points at the "\0B"
+        os.put('\0'); os.put('B'); os.write(i1.f64 ? "DM " : "FM ", 3);
+        os.put('\4'); os.write((const char *)&rows, 4); os.put('\4'); os.write((const char *)&cols, 4);
+        if (!os) { FAIL("problem writing header for output file 1"); }
+    }
+    else if (wo1 && !write_npy_header(os, i1.f64, i1.fortran, i1.fortran ? D : W, i1.fortran ? W : D)) { FAIL("problem writing header for output file 1"); }
 
     timespec tic, toc;
     clock_gettime(CLOCK_REALTIME, &tic);
@@ -269,6 +301,12 @@ int main(int argc, char *argv[])
         if (wo1 && !os.write((const char *)Y.data(), (streamsize)(W * D * sizeof(double)))) { FAIL("problem writing output file (Y)"); }
     }
     os.flush();
+    if (!scp_file.empty())
+    {
+        ofstream scp(scp_file, ios::app);
+        scp << ark_key << ' ' << ofile << ':' << ark_off << '\n';
+        if (!scp) { FAIL("problem writing scp file"); }
+    }
     clock_gettime(CLOCK_REALTIME, &toc);
     if (TOOL != TOOL_SPECTROGRAM)                                                            // generated with -t: src/kaldi_mfcc.cpp:321-322; the spectrogram tool is not (Makefile:47)
     {

@@ -100,3 +100,60 @@ def test_cli_matches_library(tmp_path):
     a = run("kaldi_mfcc", "-e", str(xf), "-o", str(tmp_path / "a.npy")); b = run("kaldi_mfcc", "-e", str(xf), "-o", str(tmp_path / "b.npy"))
     assert a.returncode == 0 and b.returncode == 0
     assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))
+
+
+def read_ark(path):
+    """minimal reader of Kaldi binary float/double matrix archives (the layout src/kaldi2bin.cpp:141-175 scans for)"""
+    out = {}
+    data = open(path, "rb").read()
+    pos = 0
+    while pos < len(data):
+        sp = data.index(b" ", pos)
+        key = data[pos:sp].decode()
+        off = sp + 1
+        assert data[off:off + 2] == b"\0B"
+        kind = data[off + 2:off + 5]
+        dt = {b"FM ": np.float32, b"DM ": np.float64}[kind]
+        assert data[off + 5] == 4 and data[off + 10] == 4
+        rows = int(np.frombuffer(data[off + 6:off + 10], dtype="<i4")[0])
+        cols = int(np.frombuffer(data[off + 11:off + 15], dtype="<i4")[0])
+        n = rows * cols * np.dtype(dt).itemsize
+        out[key] = (off, np.frombuffer(data[off + 15:off + 15 + n], dtype=dt).reshape(rows, cols))
+        pos = off + 15 + n
+    return out
+
+
+def test_ark_flags_validate_on_cpu(tmp_path):
+    x = tmp_path / "x.npy"
+    np.save(x, np.zeros(4000, np.float32))
+    r = run("kaldi_mfcc", "--append", str(x), "-o", str(tmp_path / "y.ark"))
+    assert r.returncode == 1 and "--append and --scp need --ark" in r.stderr.decode()
+    r = run("kaldi_mfcc", "--ark=a b", str(x), "-o", str(tmp_path / "y.ark"))
+    assert r.returncode == 1 and "white space" in r.stderr.decode()
+    assert "--ark=<utt-id>" in run("kaldi_fbank", "-h").stdout.decode()
+
+
+@pytest.mark.gpu
+def test_ark_and_scp_output(tmp_path):
+    from speech_amd import api
+    ark, scp = tmp_path / "feats.ark", tmp_path / "feats.scp"
+    xs = {}
+    for i, key in enumerate(("utt-a", "utt-b", "utt-c")):
+        x = signals.utterance(6000 + 1000 * i, 70 + i)
+        xs[key] = x
+        np.save(tmp_path / "x.npy", x)
+        r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "--ark=" + key, "--scp=" + str(scp), *(["--append"] if i else []),
+                str(tmp_path / "x.npy"), "-o", str(ark))
+        assert r.returncode == 0, r.stderr
+    got = read_ark(ark)
+    lines = [l.split() for l in open(scp).read().splitlines()]
+    assert [l[0] for l in lines] == ["utt-a", "utt-b", "utt-c"]
+    for key, loc in lines:
+        path, off = loc.rsplit(":", 1)
+        assert path == str(ark) and int(off) == got[key][0]
+        assert np.array_equal(got[key][1], api.kaldi_mfcc(xs[key]))
+    np.save(tmp_path / "xd.npy", xs["utt-a"].astype(np.float64))
+    r = run("kaldi_spectrogram", "-e", "-z", "-y", "-d0", "--ark=d", str(tmp_path / "xd.npy"), "-o", str(tmp_path / "d.ark"))
+    assert r.returncode == 0
+    d = read_ark(tmp_path / "d.ark")["d"][1]
+    assert d.dtype == np.float64 and np.array_equal(d, api.kaldi_spectrogram(xs["utt-a"].astype(np.float64)))
