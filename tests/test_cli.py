@@ -103,24 +103,29 @@ def test_cli_matches_library(tmp_path):
 
 
 def read_ark(path):
-    """minimal reader of Kaldi binary float/double matrix archives (the layout src/kaldi2bin.cpp:141-175 scans for)"""
-    out = {}
-    data = open(path, "rb").read()
-    pos = 0
-    while pos < len(data):
-        sp = data.index(b" ", pos)
-        key = data[pos:sp].decode()
-        off = sp + 1
-        assert data[off:off + 2] == b"\0B"
-        kind = data[off + 2:off + 5]
-        dt = {b"FM ": np.float32, b"DM ": np.float64}[kind]
-        assert data[off + 5] == 4 and data[off + 10] == 4
-        rows = int(np.frombuffer(data[off + 6:off + 10], dtype="<i4")[0])
-        cols = int(np.frombuffer(data[off + 11:off + 15], dtype="<i4")[0])
-        n = rows * cols * np.dtype(dt).itemsize
-        out[key] = (off, np.frombuffer(data[off + 15:off + 15 + n], dtype=dt).reshape(rows, cols))
-        pos = off + 15 + n
-    return out
+    from speech_amd import ark
+    return {k: (off, m) for k, off, m in ark.read_ark(path)}
+
+
+def test_ark_module_round_trip(tmp_path):
+    from speech_amd import ark
+    rng = np.random.default_rng(3)
+    feats = {"a": rng.standard_normal((7, 13)).astype(np.float32), "b-2": rng.standard_normal((0, 5)).astype(np.float32),
+             "c": rng.standard_normal((3, 4))}
+    p, scp = str(tmp_path / "f.ark"), str(tmp_path / "f.scp")
+    offs = ark.write_ark(p, feats, scp=scp)
+    more = ark.write_ark(p, {"d": feats["a"][:2]}, scp=scp, append=True)
+    got = list(ark.read_ark(p))
+    assert [g[0] for g in got] == ["a", "b-2", "c", "d"]
+    for k, off, m in got:
+        want = feats["a"][:2] if k == "d" else feats[k]
+        assert m.dtype == want.dtype and np.array_equal(m, want) and off == {**offs, **more}[k]
+    assert [(k, m.shape) for k, m in ark.read_scp(scp)] == [("a", (7, 13)), ("b-2", (0, 5)), ("c", (3, 4)), ("d", (2, 13))]
+    with pytest.raises(ValueError):
+        ark.write_ark(p, {"bad key": feats["a"]})
+    open(tmp_path / "t.ark", "wb").write(open(p, "rb").read()[:40])
+    with pytest.raises(ValueError):
+        list(ark.read_ark(tmp_path / "t.ark"))
 
 
 def test_ark_flags_validate_on_cpu(tmp_path):
