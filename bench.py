@@ -34,6 +34,7 @@ WORKLOADS = {
     "mfcc_hires40_1000x10s": dict(kind="mfcc", opts=dict(B=40, C=40, Q=22.0, lof=20.0, hif=7600.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
     # widening: the same spectrogram batch fed as 16-bit PCM (speech_batch_run_pcm16), 2 N + 4 W D bytes
     "spectrogram_pcm16_1000x10s": dict(kind="spectrogram", opts=dict(**FRONT), lens="fixed", nutt=1000, secs=10.0, pcm16=True),
+    "mfcc13_dither1_1000x10s": dict(kind="mfcc", opts=dict(B=23, C=13, Q=22.0, lof=20.0, hif=8000.0, **{**FRONT, "dither": 1.0}), lens="fixed", nutt=1000, secs=10.0),
     "plp13_1000x10s": dict(kind="plp", opts=dict(B=23, C=13, Q=22.0, compress=1.0 / 3.0, cep_scale=1.0, lof=20.0, hif=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
 }
 HEADLINE = "spectrogram_1000x10s"

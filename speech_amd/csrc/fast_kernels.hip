@@ -1,5 +1,5 @@
-// fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, even frame shift,
-// dither off).  Everything else runs on generic_kernels.hip.
+// fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, even frame shift;
+// dithered frames have their own instantiations).  Everything else runs on generic_kernels.hip.
 //
 // Unit of work: a QUAD = 4 consecutive frames of one utterance, owned by ONE 64-lane wavefront
 // (16 lanes per frame).  A 256-thread workgroup takes a tile of 16 consecutive frames, one quad per wave.
@@ -70,6 +70,9 @@ struct FastParams {
     int L, stp, D, span, ws;            // span: floats of a quad's audio, rounded up to 64; ws: floats of a wave's LDS slice (>= span, TR_WAVE)
     int snip_edges, dc0, want_pre, want_post;
     float preemph;                      // 0 when pre-emphasis is off
+    int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
+    float dither;
+    unsigned long long seed;
     int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads (spectrogram kernel), 4 = mel kinds stop after the FFT
     const float *tab;
     // mel kinds
@@ -267,9 +270,9 @@ __device__ __forceinline__ void store_run(float *y, const float *s_src, int nout
 // On return lane k2 (= lane & 15) holds, for k1 = 0..7 (and k1 = 8, meaningful in lane k2 == 0 only):
 //   pa[k1] = 4 |X[k]|^2, pb[k1] = 4 |X[256 - k]|^2 with k = k2 + 16 k1 (the factor 4 is folded into what consumes them);
 //   rawe = the frame's (floored) energy.
-template <int NZ, bool HALF>
+template <int NZ, bool HALF, bool DITHER>
 __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
-                                            float (&pa)[9], float (&pb)[9], float &rawe)
+                                            const unsigned long long dkey, float (&pa)[9], float (&pb)[9], float &rawe)
 {
     const int f = lane >> 4, n1 = lane & 15;
     const int L = p.L;
@@ -289,6 +292,19 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
         }
         else { z[n2] = f2{0.0f, 0.0f}; }
     }
+    if (DITHER)                                                             // c/kaldi_mfcc.c:243-262; the lane's pairs are i = n1 + 16 n2
+    {
+        sum2 = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            float g0, g1;
+            dither_pair(mix64(dkey + (unsigned long long)(n1 + 16 * n2)), p.dither, g0, g1);
+            z[n2] += f2{g0, g1};
+            if (n2 == NZ - 1) { z[n2].x = ve ? z[n2].x : 0.0f; z[n2].y = vo ? z[n2].y : 0.0f; }
+            sum2 += z[n2];
+        }
+    }
     float mean = 0.0f;
     if (p.dc0) { mean = row16_sum(sum2.x + sum2.y) / (float)L; }            // c/kaldi_mfcc.c:265-271
     const f2 mean2 = {mean, mean};
@@ -307,6 +323,26 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
 #pragma unroll
         for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
     }
+    if (DITHER)
+    {
+        // the dithered samples exist in registers only: the sample before a lane's even one is the odd one of the lane
+        // to its left in the same row (DPP rotate within the frame's 16 lanes), for lane 0 that of lane 15 one row up
+        float up = z[0].x;                                                  // l = 0: y[0] = d[0] - p d[0]
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            const float left = dpp_mov<0x121>(z[n2].y);                     // row_ror:1
+            const float xpm = (n1 == 0) ? up : left;
+            up = left;
+            f2 y;
+            y.x = fmaf(npre, xpm, z[n2].x);
+            y.y = fmaf(npre, z[n2].x, z[n2].y);
+            y *= win[n1 + 16 * n2];
+            if (n2 == NZ - 1) { y.x = ve ? y.x : 0.0f; y.y = vo ? y.y : 0.0f; }
+            z[n2] = y;
+        }
+    }
+    else
 #pragma unroll
     for (int n2 = 0; n2 < NZ; ++n2)
     {
@@ -480,7 +516,7 @@ __device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, 
     else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
 }
 
-template <int NZ>
+template <int NZ, bool DITHER>
 __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -497,6 +533,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     const short *xu16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
     const int nsub = ((int)tile.nframes + SUB - 1) / SUB;
+    const unsigned long long dkey_utt = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) : 0ull;
     long long s0; int need;
     int nfr = quad_geom(p, tile, wv * QF, s0, need);
     if (nfr > 0) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
@@ -515,7 +552,8 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         if (nfr > 0)
         {
             float pa[9], pb[9], rawe;
-            frame_power<NZ, false>(s_aud + f * p.stp, s_tab + opaque_zero(), s_tr, lane, p, pa, pb, rawe);
+            const unsigned long long dkey = dkey_utt + (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL;
+            frame_power<NZ, false, DITHER>(s_aud + f * p.stp, s_tab + opaque_zero(), s_tr, lane, p, dkey, pa, pb, rawe);
 
             // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything.
             // pa/pb carry 4 |X|^2: log(max(q/4, eps)) = ln2 * log2(max(q, 4 eps)) - 2 ln2.
@@ -593,7 +631,7 @@ __device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const float *brow
 
 // fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
 // Levinson-Durbin and the cepstral recursion stay in registers).
-template <int NZ, int KIND, int P>
+template <int NZ, int KIND, int P, bool DITHER>
 __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -624,7 +662,12 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
 
     const int f = lane >> 4, k2 = lane & 15;
     float pa[9], pb[9], rawe = 1.0f;
-    if (nfr > 0) { frame_power<NZ, true>(s_aud + f * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe); }
+    if (nfr > 0)
+    {
+        const unsigned long long dkey = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) +
+                                                      (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL : 0ull;
+        frame_power<NZ, true, DITHER>(s_aud + f * p.stp, s_tab, s_tr, lane, p, dkey, pa, pb, rawe);
+    }
     else
     {
 #pragma unroll
@@ -775,30 +818,35 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
 
 typedef void (*kernel_fn)(const FastParams);
 
-template <int NZ>
+template <int NZ, bool DITHER>
 kernel_fn kernel_for_kind(int kind)
 {
     switch (kind)
     {
-        case SPEECH_SPECTROGRAM: return fast_spectrogram_kernel<NZ>;
-        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0>;
-        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0>;
-        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12>;
+        case SPEECH_SPECTROGRAM: return fast_spectrogram_kernel<NZ, DITHER>;
+        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER>;
+        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER>;
+        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER>;
     }
 }
 
-kernel_fn kernel_for(int nz, int kind)
+// dithered frames have their own instantiations: the generator's temporaries would otherwise cost the plain kernels
+// 13-24 VGPRs and a resident workgroup per CU
+template <int NZ>
+kernel_fn kernel_for_nz(int kind, bool dither) { return dither ? kernel_for_kind<NZ, true>(kind) : kernel_for_kind<NZ, false>(kind); }
+
+kernel_fn kernel_for(int nz, int kind, bool dither)
 {
     switch (nz)
     {
-        case 9: return kernel_for_kind<9>(kind);
-        case 10: return kernel_for_kind<10>(kind);
-        case 11: return kernel_for_kind<11>(kind);
-        case 12: return kernel_for_kind<12>(kind);
-        case 13: return kernel_for_kind<13>(kind);
-        case 14: return kernel_for_kind<14>(kind);
-        case 15: return kernel_for_kind<15>(kind);
-        default: return kernel_for_kind<16>(kind);
+        case 9: return kernel_for_nz<9>(kind, dither);
+        case 10: return kernel_for_nz<10>(kind, dither);
+        case 11: return kernel_for_nz<11>(kind, dither);
+        case 12: return kernel_for_nz<12>(kind, dither);
+        case 13: return kernel_for_nz<13>(kind, dither);
+        case 14: return kernel_for_nz<14>(kind, dither);
+        case 15: return kernel_for_nz<15>(kind, dither);
+        default: return kernel_for_nz<16>(kind, dither);
     }
 }
 
@@ -809,7 +857,6 @@ int mel_pitch(int cols) { return 32 * ((cols + 31) / 32) + 2; }              // 
 bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
 {
     if (o.dtype != SPEECH_F32 || nfft != (size_t)NFFT) { return false; }
-    if ((float)o.dither > FLT_EPSILON) { return false; }                    // dither runs on the generic kernel
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > (size_t)NFFT || L <= (size_t)NFFT / 2u) { return false; }
     if (o.kind == SPEECH_SPECTROGRAM) { return true; }
@@ -945,6 +992,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.ws = std::max(p.span, t->kind == SPEECH_SPECTROGRAM ? TR_WAVE_C : TR_WAVE);
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
+    p.do_dither = fp.do_dither; p.dither = fp.dither; p.seed = fp.seed;
     { const char *ab = getenv("SPEECH_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }     // timing diagnostics, DESIGN.md 4.3
     p.tab = t->d_tab;
     p.melw = t->d_melw; p.mat2 = t->d_mat2; p.aux = t->d_aux;
@@ -953,7 +1001,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; }
     size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * p.ws) * sizeof(float);
     if (t->kind != SPEECH_SPECTROGRAM) { lds += (size_t)(16 + ((16 * t->D + 3) & ~3) + 16 * t->MP + 16 * 17) * sizeof(float); }
-    kernel_fn k = kernel_for(t->nz, t->kind);
+    kernel_fn k = kernel_for(t->nz, t->kind, p.do_dither != 0);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
     {

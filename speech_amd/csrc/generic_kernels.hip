@@ -2,7 +2,7 @@
 //
 // One 256-thread workgroup walks a tile of consecutive frames of one utterance; the frame lives in
 // LDS from the gather to the feature epilogue.  This path serves the *_d entry points, frame lengths
-// without a tuned kernel (nfft outside 256..2048) and dither; the tuned fp32 kernels are in
+// without a tuned kernel (nfft other than 512) and odd frame shifts; the tuned fp32 kernels are in
 // fast_kernels.hip.  Pipeline order and arithmetic follow the reference's per-frame loop
 // (c/kaldi_mfcc.c:213-334; spectrogram epilogue c/kaldi_spectrogram.c:236-251; fbank epilogue
 // c/kaldi_fbank.c:290-350; PLP tail per SURVEY.md 8(a) row P).
@@ -45,14 +45,6 @@ __device__ __forceinline__ T block_sum(T v, T *red)
         __syncthreads();
     }
     return red[0];
-}
-
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
 }
 
 template <typename T>
@@ -107,18 +99,14 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         __syncthreads();
         if (p.do_dither)
         {
-            // Gaussian pairs by Box-Muller as c/kaldi_mfcc.c:243-262, from a counter-based hash instead of a serial PCG state
+            // Gaussian pairs by Box-Muller as c/kaldi_mfcc.c:243-262, from a counter-based hash (speech_internal.hpp)
+            const unsigned long long key = mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) + (unsigned long long)w * DITHER_FRAME_MUL;
             for (int i = tid; 2 * i < L; i += NT)
             {
-                const unsigned long long h = mix64(mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) + (unsigned long long)w * 0x100000001B3ull + (unsigned long long)i);
-                const unsigned long long h2 = mix64(h);
-                T u1 = (T)((double)(unsigned)(h >> 32) * 2.3283064365386963e-10);
-                const T u2 = (T)((double)(unsigned)(h2 >> 32) * 2.3283064365386963e-10);
-                if (u1 > (T)0.99999994) { u1 = (T)0.99999994; }
-                const T R = p.dither * M<T>::sqrt((T)-2 * M<T>::log((T)1 - u1));
-                const T ang = (T)6.283185307179586476925286766559 * u2;
-                re[2 * i] += R * M<T>::cos(ang);
-                if (2 * i + 1 < L) { re[2 * i + 1] += R * M<T>::sin(ang); }
+                T g0, g1;
+                dither_pair(mix64(key + (unsigned long long)i), p.dither, g0, g1);
+                re[2 * i] += g0;
+                if (2 * i + 1 < L) { re[2 * i + 1] += g1; }
             }
             __syncthreads();
         }

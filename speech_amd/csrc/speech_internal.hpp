@@ -25,6 +25,43 @@ struct TileDesc {
     uint32_t pad;
 };
 
+// Dither (c/kaldi_mfcc.c:243-262: a Box-Muller pair per two samples of every frame, drawn afresh for each frame).  The reference
+// seeds a serial generator from the wall clock; here the pair of samples (2i, 2i+1) of frame w of utterance u takes its
+// 64 random bits from a counter-based hash, so any kernel shape draws the same noise:
+//   h = mix64(mix64(seed ^ u << 32) + w * 0x100000001B3 + i),  u1 = hi32(h) / 2^32,  u2 = lo32(h) / 2^32
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+constexpr unsigned long long DITHER_FRAME_MUL = 0x100000001B3ull;
+
+// float: hardware log2 / sqrt / sin / cos (arguments in revolutions) -- it is noise; what matters is that the tuned and the
+// generic kernels compute it with the same instructions.  g0 goes to the even sample, g1 to the odd one.
+__device__ __forceinline__ void dither_pair(unsigned long long h, float scale, float &g0, float &g1)
+{
+    float u1 = (float)(unsigned)(h >> 32) * 2.3283064365386963e-10f;
+    const float u2 = (float)(unsigned)h * 2.3283064365386963e-10f;
+    u1 = fminf(u1, 0.99999994f);
+    const float R = scale * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(1.0f - u1));     // sqrt(-2 ln(1-u1))
+    g0 = R * __builtin_amdgcn_cosf(u2);
+    g1 = R * __builtin_amdgcn_sinf(u2);
+}
+__device__ __forceinline__ void dither_pair(unsigned long long h, double scale, double &g0, double &g1)
+{
+    double u1 = (double)(unsigned)(h >> 32) * 2.3283064365386963e-10;
+    const double u2 = (double)(unsigned)h * 2.3283064365386963e-10;
+    if (u1 > 0.99999994) { u1 = 0.99999994; }
+    const double R = scale * ::sqrt(-2.0 * ::log(1.0 - u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    g0 = R * ::cos(ang);
+    g1 = R * ::sin(ang);
+}
+#endif
+
 // Everything a per-frame kernel needs besides the data (device pointers are to the plan's tables).
 template <typename T>
 struct FrameParams {

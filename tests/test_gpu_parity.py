@@ -235,13 +235,39 @@ def test_dither_is_seeded_and_has_the_right_scale():
     assert abs(np.exp(outs[0][:, 0]).mean() - 400.0) < 20.0
 
 
+@pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80, snip=0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("plp", {}),
+                                    ("mfcc", dict(fl=17.0, preemph=0.0, dc0=0, raw_energy=0, use_energy=1))])
+def test_dithered_frames_tuned_and_generic_draw_the_same_noise(kind, o):
+    """dither (c/kaldi_mfcc.c:243-262) is per frame and counter-based: the tuned kernels (noise added in registers, the
+    pre-emphasis neighbour fetched across lanes) and the generic kernel (noise added in LDS) see the same dithered frames,
+    so they agree to the bound of the undithered pair; and the noise is really there"""
+    import torch
+    lens = [24000, 4801]
+    xs = [signals.utterance(n, 90 + i) for i, n in enumerate(lens)]
+    X = torch.from_numpy(np.concatenate(xs)).cuda()
+    outs = {}
+    for dither in (0.0, 4.0):
+        for fg in (0, 1):
+            plan = api.Plan(kind, force_generic=fg, dither=dither, dither_seed=7, **o)
+            assert plan.tuned == (fg == 0)
+            b = api.Batch(plan, lens)
+            Y = torch.zeros(b.total_out, device="cuda")
+            b.run(X, Y)
+            torch.cuda.synchronize()
+            outs[dither, fg] = Y.cpu().numpy()
+    assert np.isfinite(outs[4.0, 0]).all()
+    clean = np.abs(outs[0.0, 0] - outs[0.0, 1]).max()
+    assert np.abs(outs[4.0, 0] - outs[4.0, 1]).max() <= max(2e-4, 2.0 * clean), clean
+    assert np.abs(outs[4.0, 0] - outs[0.0, 0]).max() > 1e-3
+
+
 def test_which_plans_run_on_the_tuned_kernels():
     """every BASELINE.json configuration is served by the tuned gfx950 kernels; option sets outside their envelope fall
     back to the generic kernels instead of failing"""
     tuned = [("mfcc", {}), ("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {}),
-             ("fbank", dict(fl=20.0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("fbank", dict(B=23, hif=9000.0))]
+             ("fbank", dict(fl=20.0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("fbank", dict(B=23, hif=9000.0)), ("mfcc", dict(dither=0.5))]
     generic = [("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("spectrogram", dict(sr=22050.0)), ("mfcc", dict(sr=16100.0)),
-               ("plp", dict(order=16)), ("fbank", dict(B=120)), ("mfcc", dict(dither=0.5)), ("fbank", dict(B=1))]
+               ("plp", dict(order=16)), ("fbank", dict(B=120)), ("mfcc", dict(fs=10.0625)), ("fbank", dict(B=1))]
     for kind, o in tuned:
         assert api.Plan(kind, **o).tuned, (kind, o)
     for kind, o in generic:
