@@ -49,7 +49,7 @@ namespace {
 constexpr int NT = 256;                 // threads per workgroup (4 waves)
 constexpr int QF = 4;                   // frames per wave (quad)
 constexpr int TILE = 16;                // frames per workgroup, mel kinds
-constexpr int TILE_SPEC = 64;           // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
+constexpr int TILE_SPEC = 64;  // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
 constexpr int SUB = 16;                 // frames per sub-tile
 constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
 constexpr int TR_WAVE_C = 2048;         // floats of a wave's slice when the transposition image is complex (spectrogram kernel)
@@ -73,7 +73,7 @@ struct FastParams {
     int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
     float dither;
     unsigned long long seed;
-    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads (spectrogram kernel), 4 = mel kinds stop after the FFT
+    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads (spectrogram kernel), 4 = mel kinds stop after the FFT, 8 = stores land in a 2 MB (L2-resident) window, 16 = every utterance reads utterance 0's audio (spectrogram kernel)
     const float *tab;
     // mel kinds
     const float *melw, *mat2, *aux;
@@ -84,6 +84,7 @@ struct FastParams {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -478,45 +479,48 @@ __device__ __forceinline__ int quad_geom(const FastParams &p, const TileDesc &ti
 // The next quad's audio is fetched into registers BEFORE the current quad's arithmetic and parked in the wave's LDS slice
 // after it, so the HBM latency of one quad hides behind the FFT of the previous one.  Interior quads only (an edge quad
 // of a snip_edges=0 utterance is loaded by load_span when its turn comes); loads past `need` return 0 (range check).
+#ifndef ST_AUX
+#define ST_AUX 0
+#endif
 struct Prefetch {
     float v[NPRE];                      // float samples, or the raw 16-bit PCM words (converted when parked)
-    bool on, pcm;
+    bool on;
 };
 
+// One straight run of loads whatever the case: a quad that is not prefetched gets a zero-length descriptor (its loads
+// return 0 without touching memory).  Branching around the loads, or between a float and a PCM variant of them, makes the
+// register allocator join the variants through copies -- and a copy of a load's destination is a wait for the load, right
+// where it was issued.  Hence also PCM as a template parameter.
+template <bool PCM>
 __device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane)
 {
     pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NPRE) && !(p.ablate & 2);
-    pf.pcm = (xu16 != nullptr);
-    if (pf.on && pf.pcm)
+    if (PCM)
     {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu16 + s0), 0, need * 2, BUF_FLAGS);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu16 + (pf.on ? s0 : 0)), 0, pf.on ? need * 2 : 0, BUF_FLAGS);
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) { pf.v[j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, j * 128, 0)); }
     }
-    else if (pf.on)
+    else
     {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + (pf.on ? s0 : 0)), 0, pf.on ? need * 4 : 0, BUF_FLAGS);
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) { pf.v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0)); }
     }
 }
 
+template <bool PCM>
 __device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane, int ablate)
 {
-    if (pf.on && pf.pcm)
+    if (pf.on)
     {
 #pragma unroll
-        for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = (float)(short)(unsigned short)__builtin_bit_cast(unsigned, pf.v[j]); }
-    }
-    else if (pf.on)
-    {
-#pragma unroll
-        for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = pf.v[j]; }
+        for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = PCM ? (float)(short)(unsigned short)__builtin_bit_cast(unsigned, pf.v[j]) : pf.v[j]; }
     }
     else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
 }
 
-template <int NZ, bool DITHER>
+template <int NZ, bool DITHER, bool PCM>
 __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
-    const float *xu = p.X + utt.x_off;
+    const float *xu = p.X + ((p.ablate & 16) ? 0 : utt.x_off);
     const short *xu16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
     const int nsub = ((int)tile.nframes + SUB - 1) / SUB;
@@ -540,46 +544,67 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     __syncthreads();                                                        // tables (and, wave-locally, the first span) are in LDS
 
     const int f = lane >> 4, k2 = lane & 15;
-    const int oup = (f * FB + k2) * 4;                                      // bins k2 + 16 k1, ascending
-    const int odn = (f * FB + NC - 112 - k2) * 4;                           // bins 256 - k2 - 16 k1, as 144 - k2 + 16 (7 - k1)
     for (int it = 0; it < nsub; ++it)
     {
         const int fq = it * SUB + wv * QF;                                  // this wave's quad in sub-tile `it`
         long long s0n; int needn;
         const int nfrn = quad_geom(p, tile, fq + SUB, s0n, needn);
         Prefetch pf;
-        prefetch_issue(pf, p, xu, xu16, s0n, needn, N, nfrn, lane);
+        prefetch_issue<PCM>(pf, p, xu, xu16, s0n, needn, N, nfrn, lane);
+        float pa[9], pb[9], rawe = 1.0f;
         if (nfr > 0)
         {
-            float pa[9], pb[9], rawe;
             const unsigned long long dkey = dkey_utt + (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL;
             frame_power<NZ, false, DITHER>(s_aud + f * p.stp, s_tab + opaque_zero(), s_tr, lane, p, dkey, pa, pb, rawe);
-
+        }
+        // The slice is free once the transposition image has been read (inside frame_power): park the next quad now,
+        // BEFORE this quad's stores are issued.  The loads were issued ahead of the whole FFT, and vmcnt retires in order,
+        // so waiting for them here waits for nothing younger; the stores then drain behind the next quad's arithmetic.
+        wave_sync();
+        prefetch_park<PCM>(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
+        wave_sync();
+        if (nfr > 0)
+        {
             // c/kaldi_spectrogram.c:236-251: bin 0 := energy, bins 1..255 := power, bin 256 := bin 255, log of everything.
             // pa/pb carry 4 |X|^2: log(max(q/4, eps)) = ln2 * log2(max(q, 4 eps)) - 2 ln2.
-            // For each k1 the 16 lanes of a frame hold 16 consecutive bins: every store instruction writes four 64-byte
-            // runs, and consecutive instructions complete the 128-byte lines in L2.  The descriptor covers exactly the
-            // quad's nfr x 257 outputs, so the rows of frames that do not exist are dropped by its range check.
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(p.Y + utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB), 0, (p.ablate & 1) ? 0 : nfr * FB * 4, BUF_FLAGS);
+            // The quad's 4 x 257 outputs are contiguous in Y: they are put in order in the slice behind the parked audio and
+            // leave as 16-byte stores, 1 KB of whole cache lines per instruction -- the write path to HBM is bound by
+            // requests in flight, and dword stores of 64-byte runs need eight times as many for the same bytes.
+            float *st = s_aud + p.span + f * FB;
+            st[k2] = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
             {
-                const float la = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
                 const float lb = spec_log(pb[0]);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, la), ry, oup, 0, 0);
-                if (k2 > 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64, 0); }
-                if (k2 == 1) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lb), ry, odn, 7 * 64 + 4, 0); }      // bin 256 := bin 255
+                if (k2 > 0) { st[NC - k2] = lb; }
+                if (k2 == 1) { st[NC] = lb; }                                                   // bin 256 := bin 255
             }
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1)
             {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[k1])), ry, oup, 64 * k1, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pb[k1])), ry, odn, 64 * (7 - k1), 0);
+                st[k2 + 16 * k1] = spec_log(pa[k1]);
+                st[NC - k2 - 16 * k1] = spec_log(pb[k1]);
             }
-            if (k2 == 0) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, spec_log(pa[8])), ry, oup, 128 * 4, 0); }
+            if (k2 == 0) { st[128] = spec_log(pa[8]); }
+            wave_sync();
+            const float *so = s_aud + p.span;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(p.Y + ((p.ablate & 8) ? (unsigned long long)((blockIdx.x & 31u) * TILE_SPEC + (fq & (TILE_SPEC - 1))) * FB
+                                               : utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB)), 0, (p.ablate & 1) ? 0 : nfr * FB * 4, BUF_FLAGS);
+            if (nfr == QF)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(so + 4 * lane + 256 * i);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane * 16, i * 1024, 0);
+                }
+                if (lane == 0) { __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(so + 1024), ry, 0, 4096, 0); }
+            }
+            else                                                            // the last quad of an utterance: 257, 514 or 771 floats
+            {
+                const int n = nfr * FB;
+                for (int i = lane; i < n; i += 64) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, so[i]), ry, i * 4, 0, 0); }
+            }
         }
-        wave_sync();                                                        // the transposition image has been read: the slice takes the next quad
-        prefetch_park(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
-        wave_sync();
         nfr = nfrn;
     }
 }
@@ -819,11 +844,11 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
 typedef void (*kernel_fn)(const FastParams);
 
 template <int NZ, bool DITHER>
-kernel_fn kernel_for_kind(int kind)
+kernel_fn kernel_for_kind(int kind, bool pcm)
 {
     switch (kind)
     {
-        case SPEECH_SPECTROGRAM: return fast_spectrogram_kernel<NZ, DITHER>;
+        case SPEECH_SPECTROGRAM: return pcm ? fast_spectrogram_kernel<NZ, DITHER, true> : fast_spectrogram_kernel<NZ, DITHER, false>;
         case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER>;
         case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER>;
         default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER>;
@@ -833,20 +858,20 @@ kernel_fn kernel_for_kind(int kind)
 // dithered frames have their own instantiations: the generator's temporaries would otherwise cost the plain kernels
 // 13-24 VGPRs and a resident workgroup per CU
 template <int NZ>
-kernel_fn kernel_for_nz(int kind, bool dither) { return dither ? kernel_for_kind<NZ, true>(kind) : kernel_for_kind<NZ, false>(kind); }
+kernel_fn kernel_for_nz(int kind, bool dither, bool pcm) { return dither ? kernel_for_kind<NZ, true>(kind, pcm) : kernel_for_kind<NZ, false>(kind, pcm); }
 
-kernel_fn kernel_for(int nz, int kind, bool dither)
+kernel_fn kernel_for(int nz, int kind, bool dither, bool pcm)
 {
     switch (nz)
     {
-        case 9: return kernel_for_nz<9>(kind, dither);
-        case 10: return kernel_for_nz<10>(kind, dither);
-        case 11: return kernel_for_nz<11>(kind, dither);
-        case 12: return kernel_for_nz<12>(kind, dither);
-        case 13: return kernel_for_nz<13>(kind, dither);
-        case 14: return kernel_for_nz<14>(kind, dither);
-        case 15: return kernel_for_nz<15>(kind, dither);
-        default: return kernel_for_nz<16>(kind, dither);
+        case 9: return kernel_for_nz<9>(kind, dither, pcm);
+        case 10: return kernel_for_nz<10>(kind, dither, pcm);
+        case 11: return kernel_for_nz<11>(kind, dither, pcm);
+        case 12: return kernel_for_nz<12>(kind, dither, pcm);
+        case 13: return kernel_for_nz<13>(kind, dither, pcm);
+        case 14: return kernel_for_nz<14>(kind, dither, pcm);
+        case 15: return kernel_for_nz<15>(kind, dither, pcm);
+        default: return kernel_for_nz<16>(kind, dither, pcm);
     }
 }
 
@@ -859,7 +884,8 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
     if (o.dtype != SPEECH_F32 || nfft != (size_t)NFFT) { return false; }
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > (size_t)NFFT || L <= (size_t)NFFT / 2u) { return false; }
-    if (o.kind == SPEECH_SPECTROGRAM) { return true; }
+    const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 63u) & ~(size_t)63;
+    if (o.kind == SPEECH_SPECTROGRAM) { return (TAB_FLOATS + (NT / 64) * std::max(span + QF * FB, (size_t)TR_WAVE_C)) * sizeof(float) <= 64u * 1024u; }
     if (o.B < 2u || o.B > 16u * MAX_MTILES - 2u) { return false; }
     size_t D = o.B + (o.use_energy ? 1u : 0u), cols = 0;
     if (o.kind == SPEECH_MFCC) { if (o.C > 16u * MAX_MTILES) { return false; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
@@ -870,7 +896,6 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
         D = o.C; cols = (o.B + 2u + 3u) & ~(size_t)3;
     }
     // the power / output / mel / autocorrelation tiles reuse the four wave slices
-    const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 63u) & ~(size_t)63;
     const size_t extra = 16u + ((16u * D + 3u) & ~(size_t)3) + 16u * (size_t)mel_pitch((int)cols) + 16u * 17u;
     return (TAB_FLOATS + (NT / 64) * std::max(span, (size_t)TR_WAVE) + extra) * sizeof(float) <= 64u * 1024u;
 }
@@ -989,7 +1014,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.X = fp.X; p.X16 = fp.X16; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     p.span = ((QF - 1) * fp.stp + 32 * t->nz + 63) & ~63;     // whole 64-lane load instructions fit the slice
-    p.ws = std::max(p.span, t->kind == SPEECH_SPECTROGRAM ? TR_WAVE_C : TR_WAVE);
+    p.ws = (t->kind == SPEECH_SPECTROGRAM) ? std::max(p.span + QF * FB, TR_WAVE_C) : std::max(p.span, TR_WAVE);   // spectrogram: + the quad's output, staged behind the parked audio
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.do_dither = fp.do_dither; p.dither = fp.dither; p.seed = fp.seed;
@@ -1001,7 +1026,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; }
     size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * p.ws) * sizeof(float);
     if (t->kind != SPEECH_SPECTROGRAM) { lds += (size_t)(16 + ((16 * t->D + 3) & ~3) + 16 * t->MP + 16 * 17) * sizeof(float); }
-    kernel_fn k = kernel_for(t->nz, t->kind, p.do_dither != 0);
+    kernel_fn k = kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
     {

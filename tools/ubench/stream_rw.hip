@@ -30,8 +30,14 @@ int main()
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) { best = ms; }
         }
+        // sustained: 20 launches back to back (an isolated launch ends with part of its writes still in L2 / MALL)
+        CHECK(hipEventRecord(e0));
+        for (int rep = 0; rep < 20; ++rep) { hipLaunchKernelGGL(rw, dim3(nwg), dim3(256), 0, 0, x, y, in_per_wg, out_per_wg, mode); }
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float sus; CHECK(hipEventElapsedTime(&sus, e0, e1)); sus /= 20.0f;
         const double bytes = ((mode & 1) ? (double)nwg * in_per_wg * 4 : 0.0) + ((mode & 2) ? (double)nwg * out_per_wg * 4 : 0.0);
-        printf("%s: %.3f ms, %.2f TB/s\n", mode == 1 ? "read 0.64 GB" : mode == 2 ? "write 1.03 GB" : "read 0.64 GB + write 1.03 GB", best, bytes / (best * 1e-3) / 1e12);
+        printf("%s: isolated %.3f ms, %.2f TB/s; back to back %.3f ms, %.2f TB/s\n", mode == 1 ? "read 0.64 GB" : mode == 2 ? "write 1.03 GB" : "read 0.64 GB + write 1.03 GB",
+               best, bytes / (best * 1e-3) / 1e12, sus, bytes / (sus * 1e-3) / 1e12);
     }
     return 0;
 }
