@@ -31,7 +31,7 @@
 
 namespace speech {
 
-constexpr int MAX_MTILES = 6;            // mel / cepstral tiles of 16 columns (B, C <= 96)
+constexpr int MAX_MTILES = 8;            // mel tiles of up to 16 columns (B <= 94), balanced over the 4 waves; cepstral tiles of 16 (C <= 96)
 
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[8][16] complex
@@ -40,7 +40,7 @@ struct FastTables {
     float *d_aux;      // plp: eql[B] | lift[C]
     int nz;            // ceil(L / 32): rows of 32 samples that hold data
     int kind, B, C, P, D, MP, Cp, K2, ntile_m, ntile_c;
-    int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES];
+    int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES], mel_first[MAX_MTILES], mel_cnt[MAX_MTILES];
 };
 void fast_tables_destroy(FastTables *t);
 
@@ -80,7 +80,7 @@ struct FastParams {
     int B, C, MP, Cp, K2, ntile_m, ntile_c;
     int amp, lg, use_energy, compress_mode;
     float compress;
-    int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES];
+    int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES], mel_first[MAX_MTILES], mel_cnt[MAX_MTILES];
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -217,6 +217,13 @@ __device__ __forceinline__ float floor_log(float v) { return pos_log(fmaxf(v, FL
 __device__ __forceinline__ float spec_log(float q)
 {
     return fmaf(__log2f(fmaxf(q, 4.0f * FLT_EPSILON)), 0.69314718055994530942f, -1.38629436111989061883f);
+}
+
+// two bins at a time: the scale-and-shift is one v_pk_fma_f32 (5 instructions per pair instead of 6)
+__device__ __forceinline__ f2 spec_log2(float qa, float qb)
+{
+    const f2 l = {__log2f(fmaxf(qa, 4.0f * FLT_EPSILON)), __log2f(fmaxf(qb, 4.0f * FLT_EPSILON))};
+    return __builtin_elementwise_fma(l, f2{0.69314718055994530942f, 0.69314718055994530942f}, f2{-1.38629436111989061883f, -1.38629436111989061883f});
 }
 
 // Load the wave's audio slice: `need` samples starting at utterance-relative position s0 (may be negative or run past N
@@ -571,17 +578,18 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             // leave as 16-byte stores, 1 KB of whole cache lines per instruction -- the write path to HBM is bound by
             // requests in flight, and dword stores of 64-byte runs need eight times as many for the same bytes.
             float *st = s_aud + p.span + f * FB;
-            st[k2] = (k2 == 0) ? spec_log(4.0f * rawe) : spec_log(pa[0]);
             {
-                const float lb = spec_log(pb[0]);
-                if (k2 > 0) { st[NC - k2] = lb; }
-                if (k2 == 1) { st[NC] = lb; }                                                   // bin 256 := bin 255
+                const f2 l = spec_log2((k2 == 0) ? 4.0f * rawe : pa[0], pb[0]);
+                st[k2] = l.x;
+                if (k2 > 0) { st[NC - k2] = l.y; }
+                if (k2 == 1) { st[NC] = l.y; }                                                  // bin 256 := bin 255
             }
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1)
             {
-                st[k2 + 16 * k1] = spec_log(pa[k1]);
-                st[NC - k2 - 16 * k1] = spec_log(pb[k1]);
+                const f2 l = spec_log2(pa[k1], pb[k1]);
+                st[k2 + 16 * k1] = l.x;
+                st[NC - k2 - 16 * k1] = l.y;
             }
             if (k2 == 0) { st[128] = spec_log(pa[8]); }
             wave_sync();
@@ -726,7 +734,8 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     for (int t = wv; t < p.ntile_m; t += NT / 64)
     {
         const f32x4 acc = mfma_tile4(s_pow + col * PP + p.mel_kbeg[t] + (lane >> 4), p.melw + p.mel_woff[t] + lane, p.mel_ksteps[t]);
-        const int m = 16 * t + col;
+        const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
+        const bool live = col < p.mel_cnt[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
@@ -734,16 +743,16 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
             const float v = acc[r];
             if (KIND == SPEECH_FBANK)
             {
-                if (m < p.B) { s_out[fr * p.D + eo + m] = p.lg ? floor_log(v) : v; }        // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column)
+                if (live) { s_out[fr * p.D + eo + m] = p.lg ? floor_log(v) : v; }           // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column)
             }
             else if (KIND == SPEECH_MFCC)
             {
-                if (m < p.K2) { s_mel[fr * p.MP + m] = (m < p.B) ? floor_log(v) : 0.0f; }   // c/kaldi_mfcc.c:318
+                if (live) { s_mel[fr * p.MP + m] = floor_log(v); }                          // c/kaldi_mfcc.c:318
             }
             else
             {
                 // equal loudness, compression, end duplication (c/kaldi_plp.c:339-358)
-                if (m < p.B)
+                if (live)
                 {
                     const float x = v * p.aux[m];
                     const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : __builtin_amdgcn_exp2f(p.compress * __log2f(x)));
@@ -755,6 +764,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
         }
     }
     if (KIND == SPEECH_FBANK && eo && tid < 16) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
+    if (KIND == SPEECH_MFCC && tid < 64) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
     __syncthreads();
 
     if (KIND == SPEECH_MFCC)
@@ -886,9 +896,9 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > (size_t)NFFT || L <= (size_t)NFFT / 2u) { return false; }
     const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 63u) & ~(size_t)63;
     if (o.kind == SPEECH_SPECTROGRAM) { return (TAB_FLOATS + (NT / 64) * std::max(span + QF * FB, (size_t)TR_WAVE_C)) * sizeof(float) <= 64u * 1024u; }
-    if (o.B < 2u || o.B > 16u * MAX_MTILES - 2u) { return false; }
+    if (o.B < 2u || o.B > 94u) { return false; }
     size_t D = o.B + (o.use_energy ? 1u : 0u), cols = 0;
-    if (o.kind == SPEECH_MFCC) { if (o.C > 16u * MAX_MTILES) { return false; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
+    if (o.kind == SPEECH_MFCC) { if (o.C > 96u) { return false; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
     if (o.kind == SPEECH_PLP)
     {
         const size_t P = (o.lpc_order > 0u) ? o.lpc_order : o.C - 1u;
@@ -937,32 +947,45 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, s
     if (o.kind != SPEECH_SPECTROGRAM)
     {
         const int Bi = (int)B, Ci = (int)C;
-        t->B = Bi; t->ntile_m = (Bi + 15) / 16;
+        t->B = Bi;
         // the kernels hand over 4 |X|^2 (2 |X| with amp): the exact power-of-two factor is folded into the weights
         const float wscale = (o.kind == SPEECH_FBANK && o.amp) ? 0.5f : 0.25f;
         std::vector<int> off(B, 0);
         for (size_t b = 1; b < B; ++b) { off[b] = off[b - 1] + num[b - 1]; }
+        // effective source bin of each column: fbank's last column is a copy of the one before (c/kaldi_fbank.c:350)
+        auto src_of = [&](int m) { return (o.kind == SPEECH_FBANK && m == Bi - 1 && Bi >= 2) ? Bi - 2 : m; };
+        // k-range of columns [i, j): k-steps in whole groups of four (mfma_tile4); the extra bins carry zero weights
+        auto k_range = [&](int i, int j, int &kb, int &ks) {
+            int kmin = 1 << 30, kmax = -1;
+            for (int m = i; m < j; ++m) { const int b = src_of(m); if (num[b] > 0) { kmin = std::min(kmin, beg[b]); kmax = std::max(kmax, beg[b] + num[b]); } }
+            ks = 0; kb = 0;
+            if (kmax > kmin) { ks = (((kmax - kmin + 3) / 4) + 3) & ~3; kb = kmin; if (kb + 4 * ks > PP) { kb = PP - 4 * ks; } }
+        };
+        // Columns are dealt to tiles of at most 16 so that the LONGEST k-loop is as short as possible: with equal column
+        // counts the high tiles (wide triangles) take 2-3x the k-steps of the low ones and their waves finish last.
+        // 4 tiles (one per wave) up to 64 columns, else 8.
+        const int T = (Bi <= 64) ? std::min(4, Bi) : 8;
+        std::vector<std::vector<int>> best(T + 1, std::vector<int>(Bi + 1, 1 << 30)), from(T + 1, std::vector<int>(Bi + 1, -1));
+        best[0][0] = 0;
+        for (int tl = 1; tl <= T; ++tl) { for (int j = tl; j <= Bi; ++j) { for (int i = std::max(tl - 1, j - 16); i < j; ++i) {
+            if (best[tl - 1][i] >= (1 << 30)) { continue; }
+            int kb, ks; k_range(i, j, kb, ks);
+            const int c = std::max(best[tl - 1][i], ks);
+            if (c < best[tl][j]) { best[tl][j] = c; from[tl][j] = i; } } } }
+        if (best[T][Bi] >= (1 << 30)) { delete t; return nullptr; }
+        t->ntile_m = T;
+        { int j = Bi; for (int tl = T; tl >= 1; --tl) { const int i = from[tl][j]; t->mel_first[tl - 1] = i; t->mel_cnt[tl - 1] = j - i; j = i; } }
         for (int tl = 0; tl < t->ntile_m; ++tl)
         {
-            // effective source bin of each column: fbank's last column is a copy of the one before (c/kaldi_fbank.c:350)
-            int src[16], kmin = 1 << 30, kmax = -1;
-            for (int c = 0; c < 16; ++c)
-            {
-                const int m = 16 * tl + c;
-                src[c] = (m < Bi) ? ((o.kind == SPEECH_FBANK && m == Bi - 1) ? Bi - 2 : m) : -1;
-                if (src[c] >= 0 && num[src[c]] > 0) { kmin = std::min(kmin, beg[src[c]]); kmax = std::max(kmax, beg[src[c]] + num[src[c]]); }
-            }
-            int ks = 0, kb = 0;
-            // k-steps in whole groups of four (mfma_tile4); the extra bins carry zero weights and stay inside the 258-column tile
-            if (kmax > kmin) { ks = (((kmax - kmin + 3) / 4) + 3) & ~3; kb = kmin; if (kb + 4 * ks > PP) { kb = PP - 4 * ks; } }
+            int kb, ks; k_range(t->mel_first[tl], t->mel_first[tl] + t->mel_cnt[tl], kb, ks);
             if (kb < 0) { delete t; return nullptr; }                       // a tile spanning more than 256 bins: generic kernels
             t->mel_kbeg[tl] = kb; t->mel_ksteps[tl] = ks; t->mel_woff[tl] = (int)melw.size();
             melw.resize(melw.size() + (size_t)64 * ks, 0.0f);
             float *w = melw.data() + t->mel_woff[tl];
-            for (int c = 0; c < 16; ++c)
+            for (int c = 0; c < t->mel_cnt[tl]; ++c)
             {
-                if (src[c] < 0) { continue; }
-                for (int j = 0; j < num[src[c]]; ++j) { w[(beg[src[c]] + j - kb) * 16 + c] = wscale * f2b[off[src[c]] + j]; }
+                const int b = src_of(t->mel_first[tl] + c);
+                for (int j = 0; j < num[b]; ++j) { w[(beg[b] + j - kb) * 16 + c] = wscale * f2b[off[b] + j]; }
             }
         }
         if (melw.empty()) { melw.push_back(0.0f); }
@@ -1023,7 +1046,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.melw = t->d_melw; p.mat2 = t->d_mat2; p.aux = t->d_aux;
     p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;
     p.amp = fp.amp; p.lg = fp.lg; p.use_energy = fp.use_energy; p.compress_mode = fp.compress_mode; p.compress = fp.compress;
-    for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; }
+    for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; p.mel_first[i] = t->mel_first[i]; p.mel_cnt[i] = t->mel_cnt[i]; }
     size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * p.ws) * sizeof(float);
     if (t->kind != SPEECH_SPECTROGRAM) { lds += (size_t)(16 + ((16 * t->D + 3) & ~3) + 16 * t->MP + 16 * 17) * sizeof(float); }
     kernel_fn k = kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
