@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspeech.so")
+LIB_PATH = os.environ.get("SPEECH_AMD_LIB") or os.path.join(_HERE, "lib", "libspeech.so")   # the override is for A/B timing of builds
 
 KINDS = {"spectrogram": 0, "fbank": 1, "mfcc": 2, "plp": 3}
 F32, F64 = 0, 1
