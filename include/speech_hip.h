@@ -87,6 +87,28 @@ int speech_batch_run_timed(speech_batch *batch, const void *X_dev, void *Y_dev, 
    input bytes over PCIe and HBM.  kernel_ms may be NULL (asynchronous) or receives the per-frame kernel's duration. */
 int speech_batch_run_pcm16(speech_batch *batch, const short *X16_dev, void *Y_dev, void *stream, float *kernel_ms);
 
+/* Widening: corpus post-processing on a batch's packed features Y_dev (frame-major W x D per utterance,
+   the layout speech_batch_run writes).  The reference's only post-pass is mn0, the per-utterance mean subtraction
+   (c/kaldi_fbank.c:355-370, c/kaldi_mfcc.c:337-352); these generalise it to Kaldi's apply-cmvn, add-deltas and
+   splice-feats.  All enqueue on `stream`; speech_batch_stats also waits for it.  Not thread-safe per batch (they share
+   the batch's moment buffer).
+   - stats: per-feature sum and sum of squares over every frame of the batch, in double, into host arrays of D; *frames =
+     number of frames.  A multi-GPU caller adds these over ranks (the one place this path has a collective: 2 D + 1 doubles)
+     and applies the result with speech_batch_affine.
+   - cmvn: per utterance, in place: subtract the mean; norm_vars != 0 also divides by the standard deviation (variance
+     floored at 1e-20).  norm_vars == 0 is mn0 on D columns.
+   - affine: in place y = y * scale[d] + offset[d] (multiply, then add, each rounded in the plan's dtype); scale / offset
+     are host arrays of D doubles.
+   - add_deltas: Z[t] = [Y[t] | delta | delta-delta | ...], D (order + 1) columns, order in [0 3], window in [1 5], filters
+     and edge clamping as Kaldi's DeltaFeatures; utterance u of Z starts at (order + 1) x its offset in Y.
+   - splice: Z[t] = [Y[t-left] | ... | Y[t+right]] with the frame index clamped to the utterance, D (left + right + 1)
+     columns; utterance u of Z starts at (left + right + 1) x its offset in Y.  Z must not alias Y. */
+int speech_batch_stats(speech_batch *batch, const void *Y_dev, double *sum, double *sumsq, unsigned long long *frames, void *stream);
+int speech_batch_cmvn(speech_batch *batch, void *Y_dev, int norm_vars, void *stream);
+int speech_batch_affine(speech_batch *batch, void *Y_dev, const double *scale, const double *offset, void *stream);
+int speech_batch_add_deltas(speech_batch *batch, const void *Y_dev, void *Z_dev, int order, int window, void *stream);
+int speech_batch_splice(speech_batch *batch, const void *Y_dev, void *Z_dev, int left, int right, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ EXT_SYMBOLS = [
     "speech_plan_create", "speech_plan_destroy", "speech_plan_sizes", "speech_plan_num_frames",
     "speech_batch_create", "speech_batch_destroy", "speech_batch_totals", "speech_batch_offsets",
     "speech_batch_run", "speech_batch_run_timed", "speech_batch_run_pcm16",
+    "speech_batch_stats", "speech_batch_cmvn", "speech_batch_affine", "speech_batch_add_deltas", "speech_batch_splice",
 ]
 
 
@@ -86,6 +87,12 @@ def load():
     lib.speech_batch_run.argtypes = [vp, vp, vp, vp]; lib.speech_batch_run.restype = i
     lib.speech_batch_run_timed.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]; lib.speech_batch_run_timed.restype = i
     lib.speech_batch_run_pcm16.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]; lib.speech_batch_run_pcm16.restype = i
+    pd = C.POINTER(C.c_double)
+    lib.speech_batch_stats.argtypes = [vp, vp, pd, pd, C.POINTER(C.c_ulonglong), vp]; lib.speech_batch_stats.restype = i
+    lib.speech_batch_cmvn.argtypes = [vp, vp, i, vp]; lib.speech_batch_cmvn.restype = i
+    lib.speech_batch_affine.argtypes = [vp, vp, pd, pd, vp]; lib.speech_batch_affine.restype = i
+    lib.speech_batch_add_deltas.argtypes = [vp, vp, vp, i, i, vp]; lib.speech_batch_add_deltas.restype = i
+    lib.speech_batch_splice.argtypes = [vp, vp, vp, i, i, vp]; lib.speech_batch_splice.restype = i
     _lib = lib
     return lib
 

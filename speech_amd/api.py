@@ -189,6 +189,45 @@ class Batch:
             raise SpeechError(_lib.last_error())
         return None
 
+    # ---- corpus post-processing on the packed features (include/speech_hip.h) ----
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SpeechError(_lib.last_error())
+
+    def stats(self, Y, stream=None):
+        """per-feature (sum, sum of squares, frames) over the batch, float64 numpy arrays of D; waits for the stream"""
+        D = self.plan.D
+        s, q, n = np.zeros(D), np.zeros(D), C.c_ulonglong()
+        pd = C.POINTER(C.c_double)
+        self._check(self._lib.speech_batch_stats(self._h, C.c_void_p(Y.data_ptr()), s.ctypes.data_as(pd), q.ctypes.data_as(pd), C.byref(n),
+                                                 C.c_void_p(stream) if stream else None))
+        return s, q, int(n.value)
+
+    def cmvn(self, Y, norm_vars=False, stream=None):
+        """per-utterance mean (and variance) normalisation, in place"""
+        self._check(self._lib.speech_batch_cmvn(self._h, C.c_void_p(Y.data_ptr()), int(bool(norm_vars)), C.c_void_p(stream) if stream else None))
+
+    def affine(self, Y, scale, offset, stream=None):
+        """y = y * scale[d] + offset[d] in place (e.g. corpus-wide CMVN from merged stats)"""
+        D = self.plan.D
+        sc, of = np.ascontiguousarray(scale, dtype=np.float64), np.ascontiguousarray(offset, dtype=np.float64)
+        if sc.shape != (D,) or of.shape != (D,):
+            raise ValueError("scale and offset must have shape (%d,)" % D)
+        pd = C.POINTER(C.c_double)
+        self._check(self._lib.speech_batch_affine(self._h, C.c_void_p(Y.data_ptr()), sc.ctypes.data_as(pd), of.ctypes.data_as(pd),
+                                                  C.c_void_p(stream) if stream else None))
+
+    def add_deltas(self, Y, Z, order=2, window=2, stream=None):
+        """Z (total_out * (order + 1) elements) = features with delta .. delta^order appended, Kaldi add-deltas"""
+        self._check(self._lib.speech_batch_add_deltas(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(order), int(window),
+                                                      C.c_void_p(stream) if stream else None))
+
+    def splice(self, Y, Z, left=4, right=4, stream=None):
+        """Z (total_out * (left + right + 1) elements) = frames spliced with their neighbours, Kaldi splice-feats"""
+        self._check(self._lib.speech_batch_splice(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(left), int(right),
+                                                  C.c_void_p(stream) if stream else None))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.speech_batch_destroy(self._h)
@@ -199,6 +238,33 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+def merge_stats(s, q, n, group=None):
+    """Corpus-wide statistics over ranks: the one exchange step of this path.  Adds the per-rank
+    (sum, sumsq, frames) of Batch.stats with ONE all-reduce of 2 D + 1 float64 values over `group` (torch.distributed:
+    RCCL between GPUs, gloo in the CPU tests); without an initialised process group it returns its inputs."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return np.asarray(s, dtype=np.float64), np.asarray(q, dtype=np.float64), int(n)
+    D = len(s)
+    buf = torch.from_numpy(np.concatenate([np.asarray(s, np.float64), np.asarray(q, np.float64), [float(n)]]))
+    if dist.get_backend(group) == "nccl":
+        buf = buf.cuda()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    out = buf.cpu().numpy()
+    return out[:D].copy(), out[D:2 * D].copy(), int(round(out[2 * D]))
+
+
+def cmvn_from_stats(s, q, n, norm_vars=True, var_floor=1.0e-20):
+    """(scale, offset) of apply-cmvn from merged statistics: y = (x - mean) / std = x * scale + offset"""
+    s, q = np.asarray(s, np.float64), np.asarray(q, np.float64)
+    mean = s / float(n)
+    scale = np.ones_like(mean)
+    if norm_vars:
+        scale = 1.0 / np.sqrt(np.maximum(q / float(n) - mean * mean, var_floor))
+    return scale, -mean * scale
 
 
 def shard_utterances(n_samples, world_size):

@@ -247,6 +247,7 @@ struct speech_batch {
     UttDesc *d_utts;
     TileDesc *d_tiles;
     float *d_scratch;
+    double *d_mom;               // post-processing: [nutt][2][D] moments, then [2][D] scale / offset (allocated on first use)
     size_t total_samples, total_out, total_frames;
     hipEvent_t ev0, ev1;
 };
@@ -489,7 +490,7 @@ int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const s
     if (nutt > 0xFFFFFFFFull) { return fail(fn, "too many utterances"); }
     speech_batch *b = new (std::nothrow) speech_batch();
     if (!b) { return fail(fn, "out of host memory"); }
-    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_scratch = nullptr; b->ev0 = b->ev1 = nullptr;
+    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_scratch = nullptr; b->d_mom = nullptr; b->ev0 = b->ev1 = nullptr;
     b->total_samples = b->total_out = b->total_frames = 0;
     const int tile = p->tuned ? fast_tile_frames(p->o) : GENERIC_TILE_FRAMES;
     const char *kfn = kind_name(p->o.kind, p->o.dtype);
@@ -538,6 +539,7 @@ void speech_batch_destroy(speech_batch *b)
     if (b->d_utts) { (void)hipFree(b->d_utts); }
     if (b->d_tiles) { (void)hipFree(b->d_tiles); }
     if (b->d_scratch) { (void)hipFree(b->d_scratch); }
+    if (b->d_mom) { (void)hipFree(b->d_mom); }
     if (b->ev0) { (void)hipEventDestroy(b->ev0); }
     if (b->ev1) { (void)hipEventDestroy(b->ev1); }
     delete b;
@@ -576,6 +578,142 @@ int speech_batch_run_timed(speech_batch *b, const void *X, void *Y, void *stream
 {
     if (!kernel_ms) { return fail("speech_batch_run_timed", "null kernel_ms"); }
     return batch_run(b, X, nullptr, Y, stream, kernel_ms);
+}
+
+// ---- corpus post-processing on the packed features; generalises mn0, c/kaldi_fbank.c:355-370 ----
+
+namespace {
+
+int post_begin(const char *fn, const speech_batch *b, PostParams *pp, uint32_t *max_frames)
+{
+    if (!b || !b->plan) { return fail(fn, "null batch"); }
+    memset(pp, 0, sizeof(*pp));
+    pp->utts = b->d_utts; pp->nutt = (uint32_t)b->utts.size(); pp->D = (int)b->plan->sz.D; pp->rows_per_wg = 128;
+    unsigned long long mw = 0;
+    for (const UttDesc &u : b->utts) { mw = std::max(mw, u.W); }
+    *max_frames = (uint32_t)mw;
+    return 0;
+}
+
+int post_moments(const char *fn, speech_batch *b, const void *Y, PostParams *pp, hipStream_t s)
+{
+    const size_t nd = (size_t)pp->nutt * 2 * pp->D + 2 * (size_t)pp->D;
+    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, nd * sizeof(double))); }
+    pp->Yin = Y; pp->mom = b->d_mom;
+    HIP_TRY(fn, launch_post(POST_MOMENTS, b->plan->o.dtype == SPEECH_F64, *pp, 0, s));
+    return 0;
+}
+
+}  // namespace
+
+int speech_batch_stats(speech_batch *b, const void *Y, double *sum, double *sumsq, unsigned long long *frames, void *stream)
+{
+    const char *fn = "speech_batch_stats";
+    PostParams pp; uint32_t mw;
+    if (post_begin(fn, b, &pp, &mw)) { return 1; }
+    if (!sum || !sumsq) { return fail(fn, "null output"); }
+    const int D = pp.D;
+    for (int d = 0; d < D; ++d) { sum[d] = 0.0; sumsq[d] = 0.0; }
+    if (frames) { *frames = (unsigned long long)b->total_frames; }
+    if (pp.nutt == 0 || b->total_frames == 0) { return 0; }
+    if (!Y) { return fail(fn, "null device pointer"); }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    hipStream_t s = (hipStream_t)stream;
+    if (post_moments(fn, b, Y, &pp, s)) { return 1; }
+    std::vector<double> h((size_t)pp.nutt * 2 * D);
+    HIP_TRY(fn, hipMemcpyAsync(h.data(), b->d_mom, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(fn, hipStreamSynchronize(s));
+    for (uint32_t u = 0; u < pp.nutt; ++u)                                   // utterance order: the same sums on every run
+    {
+        for (int d = 0; d < D; ++d) { sum[d] += h[(size_t)u * 2 * D + d]; sumsq[d] += h[(size_t)u * 2 * D + D + d]; }
+    }
+    return 0;
+}
+
+int speech_batch_cmvn(speech_batch *b, void *Y, int norm_vars, void *stream)
+{
+    const char *fn = "speech_batch_cmvn";
+    PostParams pp; uint32_t mw;
+    if (post_begin(fn, b, &pp, &mw)) { return 1; }
+    if (pp.nutt == 0 || b->total_frames == 0) { return 0; }
+    if (!Y) { return fail(fn, "null device pointer"); }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    hipStream_t s = (hipStream_t)stream;
+    if (post_moments(fn, b, Y, &pp, s)) { return 1; }
+    pp.Y = Y; pp.mode = 1; pp.norm_vars = norm_vars ? 1 : 0;
+    HIP_TRY(fn, launch_post(POST_AFFINE, b->plan->o.dtype == SPEECH_F64, pp, mw, s));
+    return 0;
+}
+
+int speech_batch_affine(speech_batch *b, void *Y, const double *scale, const double *offset, void *stream)
+{
+    const char *fn = "speech_batch_affine";
+    PostParams pp; uint32_t mw;
+    if (post_begin(fn, b, &pp, &mw)) { return 1; }
+    if (!scale || !offset) { return fail(fn, "null scale / offset"); }
+    if (pp.nutt == 0 || b->total_frames == 0) { return 0; }
+    if (!Y) { return fail(fn, "null device pointer"); }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t D = (size_t)pp.D, nd = (size_t)pp.nutt * 2 * D + 2 * D;
+    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, nd * sizeof(double))); }
+    double *d_aff = b->d_mom + (size_t)pp.nutt * 2 * D;
+    std::vector<double> h(2 * D);
+    for (size_t d = 0; d < D; ++d) { h[d] = scale[d]; h[D + d] = offset[d]; }
+    HIP_TRY(fn, hipMemcpyAsync(d_aff, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(fn, hipStreamSynchronize(s));                                    // h leaves scope
+    pp.Y = Y; pp.mode = 0; pp.scale = d_aff; pp.offset = d_aff + D;
+    HIP_TRY(fn, launch_post(POST_AFFINE, b->plan->o.dtype == SPEECH_F64, pp, mw, s));
+    return 0;
+}
+
+int speech_batch_add_deltas(speech_batch *b, const void *Y, void *Z, int order, int window, void *stream)
+{
+    const char *fn = "speech_batch_add_deltas";
+    PostParams pp; uint32_t mw;
+    if (post_begin(fn, b, &pp, &mw)) { return 1; }
+    if (order < 0 || order > POST_MAX_ORDER) { return fail(fn, "order must be in [0 %d]", POST_MAX_ORDER); }
+    if (window < 1 || window > POST_MAX_WINDOW) { return fail(fn, "window must be in [1 %d]", POST_MAX_WINDOW); }
+    if (pp.nutt == 0 || b->total_frames == 0) { return 0; }
+    if (!Y || !Z) { return fail(fn, "null device pointer"); }
+    if (Y == Z) { return fail(fn, "add_deltas cannot run in place"); }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    // filters as Kaldi's DeltaFeatures: scales[0] = {1}; scales[k] = scales[k-1] convolved with j / sum(j^2), j = -window..window
+    pp.dscale[0][0] = 1.0;
+    for (int k = 1; k <= order; ++k)
+    {
+        const int ph = (k - 1) * window, ch = k * window;
+        double norm = 0.0;
+        for (int j = -window; j <= window; ++j)
+        {
+            norm += (double)(j * j);
+            for (int i = -ph; i <= ph; ++i) { pp.dscale[k][j + i + ch] += (double)j * pp.dscale[k - 1][i + ph]; }
+        }
+        for (int i = 0; i <= 2 * ch; ++i) { pp.dscale[k][i] /= norm; }
+    }
+    pp.Yin = Y; pp.Y = Z; pp.order = order; pp.window = window;
+    HIP_TRY(fn, launch_post(POST_DELTAS, b->plan->o.dtype == SPEECH_F64, pp, mw, (hipStream_t)stream));
+    return 0;
+}
+
+int speech_batch_splice(speech_batch *b, const void *Y, void *Z, int left, int right, void *stream)
+{
+    const char *fn = "speech_batch_splice";
+    PostParams pp; uint32_t mw;
+    if (post_begin(fn, b, &pp, &mw)) { return 1; }
+    if (left < 0 || right < 0 || left > 64 || right > 64) { return fail(fn, "left and right context must be in [0 64]"); }
+    if (pp.nutt == 0 || b->total_frames == 0) { return 0; }
+    if (!Y || !Z) { return fail(fn, "null device pointer"); }
+    if (Y == Z) { return fail(fn, "splice cannot run in place"); }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    pp.Yin = Y; pp.Y = Z; pp.left = left; pp.right = right;
+    HIP_TRY(fn, launch_post(POST_SPLICE, b->plan->o.dtype == SPEECH_F64, pp, mw, (hipStream_t)stream));
+    return 0;
 }
 
 }  // extern "C"

@@ -105,6 +105,23 @@ struct MeanNormParams {
     int D;
 };
 
+// corpus post-processing (post_kernels.hip)
+constexpr int POST_MAX_ORDER = 3, POST_MAX_WINDOW = 5, POST_MAX_TAPS = 2 * POST_MAX_ORDER * POST_MAX_WINDOW + 1;
+enum { POST_MOMENTS = 0, POST_AFFINE = 1, POST_DELTAS = 2, POST_SPLICE = 3 };
+struct PostParams {
+    void *Y;                     // in place (affine) or output (deltas, splice)
+    const void *Yin;             // input (moments, deltas, splice)
+    const UttDesc *utts;
+    uint32_t nutt;
+    int D, rows_per_wg;
+    double *mom;                 // [nutt][2][D]: column sums and sums of squares per utterance
+    const double *scale, *offset;    // affine mode 0: [D] each (device)
+    int mode, norm_vars;
+    int order, window, left, right;
+    double dscale[POST_MAX_ORDER + 1][POST_MAX_TAPS];    // delta filters, centred: order k has 2 k window + 1 taps
+};
+hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_frames, hipStream_t s);
+
 // launchers (defined in the kernel translation units)
 hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s);
 hipError_t launch_generic_f64(const FrameParams<double> &p, hipStream_t s);
