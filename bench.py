@@ -92,6 +92,7 @@ class Work:
 
     def sustained_ms(self, steps):
         """average launch duration of `steps` back-to-back launches, HIP events on the launch stream (torch's current one)"""
+        import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
