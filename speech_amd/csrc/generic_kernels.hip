@@ -298,23 +298,6 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
     }
 }
 
-// mn0: subtract the per-feature mean over the utterance's frames, D wide, summed last frame first
-// (intended behaviour of c/kaldi_fbank.c:355-370; see DESIGN.md "mn0").
-template <typename T>
-__global__ __launch_bounds__(NT) void mean_norm_kernel(const MeanNormParams p)
-{
-    const UttDesc utt = p.utts[blockIdx.x];
-    T *Y = reinterpret_cast<T *>(p.Y) + utt.y_off;
-    const long long W = (long long)utt.W;
-    for (int d = threadIdx.x; d < p.D; d += NT)
-    {
-        T s = (T)0;
-        for (long long w = W - 1; w >= 0; --w) { s += Y[w * p.D + d]; }
-        const T mn = s / (T)W;
-        for (long long w = 0; w < W; ++w) { Y[w * p.D + d] -= mn; }
-    }
-}
-
 template <typename T>
 hipError_t launch_generic(const FrameParams<T> &p, hipStream_t s)
 {
@@ -341,19 +324,5 @@ size_t generic_lds_bytes(int nfft, int B, int C, int P, size_t elem)
 
 hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s) { return launch_generic<float>(p, s); }
 hipError_t launch_generic_f64(const FrameParams<double> &p, hipStream_t s) { return launch_generic<double>(p, s); }
-
-hipError_t launch_mean_norm_f32(const MeanNormParams &p, hipStream_t s)
-{
-    if (p.nutt == 0) { return hipSuccess; }
-    hipLaunchKernelGGL(mean_norm_kernel<float>, dim3(p.nutt), dim3(NT), 0, s, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_mean_norm_f64(const MeanNormParams &p, hipStream_t s)
-{
-    if (p.nutt == 0) { return hipSuccess; }
-    hipLaunchKernelGGL(mean_norm_kernel<double>, dim3(p.nutt), dim3(NT), 0, s, p);
-    return hipGetLastError();
-}
 
 }  // namespace speech

@@ -344,6 +344,28 @@ void fill_params(const speech_batch *b, const void *X, const short *X16, void *Y
     fp->mel_out = nullptr;
 }
 
+// shared by mn0 and the post-processing entry points
+int post_begin(const char *fn, const speech_batch *b, PostParams *pp, uint32_t *max_frames)
+{
+    if (!b || !b->plan) { return fail(fn, "null batch"); }
+    memset(pp, 0, sizeof(*pp));
+    pp->utts = b->d_utts; pp->nutt = (uint32_t)b->utts.size(); pp->D = (int)b->plan->sz.D; pp->rows_per_wg = 128;
+    unsigned long long mw = 0;
+    for (const UttDesc &u : b->utts) { mw = std::max(mw, u.W); }
+    *max_frames = (uint32_t)mw;
+    return 0;
+}
+
+int post_moments(const char *fn, speech_batch *b, const void *Y, PostParams *pp, hipStream_t s)
+{
+    const size_t nd = (size_t)pp->nutt * 2 * pp->D + 2 * (size_t)pp->D;
+    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, nd * sizeof(double))); }
+    pp->Yin = Y; pp->mom = b->d_mom;
+    HIP_TRY(fn, launch_post(POST_MOMENTS, b->plan->o.dtype == SPEECH_F64, *pp, 0, s));
+    return 0;
+}
+
+
 int batch_run(speech_batch *b, const void *X, const short *X16, void *Y, void *stream, float *kernel_ms)
 {
     const char *fn = "speech_batch_run";
@@ -380,8 +402,13 @@ int batch_run(speech_batch *b, const void *X, const short *X16, void *Y, void *s
     }
     if (p->o.mn0)
     {
-        MeanNormParams mp; mp.Y = Y; mp.utts = b->d_utts; mp.nutt = (uint32_t)b->utts.size(); mp.D = (int)p->sz.D;
-        HIP_TRY(fn, p->o.dtype == SPEECH_F64 ? launch_mean_norm_f64(mp, s) : launch_mean_norm_f32(mp, s));
+        // per-feature mean over the utterance's frames, D wide (intended behaviour of c/kaldi_fbank.c:355-370, DESIGN.md "mn0"):
+        // the coalesced moments + affine passes of the post-processing kernels, mean accumulated in double
+        PostParams pp; uint32_t mw;
+        if (post_begin(fn, b, &pp, &mw)) { return 1; }
+        if (post_moments(fn, b, Y, &pp, s)) { return 1; }
+        pp.Y = Y; pp.mode = 1; pp.norm_vars = 0;
+        HIP_TRY(fn, launch_post(POST_AFFINE, p->o.dtype == SPEECH_F64, pp, mw, s));
     }
     if (kernel_ms)
     {
@@ -581,30 +608,6 @@ int speech_batch_run_timed(speech_batch *b, const void *X, void *Y, void *stream
 }
 
 // ---- corpus post-processing on the packed features; generalises mn0, c/kaldi_fbank.c:355-370 ----
-
-namespace {
-
-int post_begin(const char *fn, const speech_batch *b, PostParams *pp, uint32_t *max_frames)
-{
-    if (!b || !b->plan) { return fail(fn, "null batch"); }
-    memset(pp, 0, sizeof(*pp));
-    pp->utts = b->d_utts; pp->nutt = (uint32_t)b->utts.size(); pp->D = (int)b->plan->sz.D; pp->rows_per_wg = 128;
-    unsigned long long mw = 0;
-    for (const UttDesc &u : b->utts) { mw = std::max(mw, u.W); }
-    *max_frames = (uint32_t)mw;
-    return 0;
-}
-
-int post_moments(const char *fn, speech_batch *b, const void *Y, PostParams *pp, hipStream_t s)
-{
-    const size_t nd = (size_t)pp->nutt * 2 * pp->D + 2 * (size_t)pp->D;
-    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, nd * sizeof(double))); }
-    pp->Yin = Y; pp->mom = b->d_mom;
-    HIP_TRY(fn, launch_post(POST_MOMENTS, b->plan->o.dtype == SPEECH_F64, *pp, 0, s));
-    return 0;
-}
-
-}  // namespace
 
 int speech_batch_stats(speech_batch *b, const void *Y, double *sum, double *sumsq, unsigned long long *frames, void *stream)
 {

@@ -98,13 +98,6 @@ struct FrameParams {
     T *mel_out;                  // optional scratch [frames x B] (plp two-kernel path), else nullptr
 };
 
-struct MeanNormParams {
-    void *Y;
-    const UttDesc *utts;
-    uint32_t nutt;
-    int D;
-};
-
 // corpus post-processing (post_kernels.hip)
 constexpr int POST_MAX_ORDER = 3, POST_MAX_WINDOW = 5, POST_MAX_TAPS = 2 * POST_MAX_ORDER * POST_MAX_WINDOW + 1;
 enum { POST_MOMENTS = 0, POST_AFFINE = 1, POST_DELTAS = 2, POST_SPLICE = 3 };
@@ -126,8 +119,6 @@ hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_fra
 hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s);
 hipError_t launch_generic_f64(const FrameParams<double> &p, hipStream_t s);
 size_t generic_lds_bytes(int nfft, int B, int C, int P, size_t elem);
-hipError_t launch_mean_norm_f32(const MeanNormParams &p, hipStream_t s);
-hipError_t launch_mean_norm_f64(const MeanNormParams &p, hipStream_t s);
 
 constexpr int GENERIC_TILE_FRAMES = 8;
 constexpr int GENERIC_MAX_NFFT = 8192;
