@@ -35,6 +35,7 @@ WORKLOADS = {
     # widening: the same spectrogram batch fed as 16-bit PCM (speech_batch_run_pcm16), 2 N + 4 W D bytes
     "spectrogram_pcm16_1000x10s": dict(kind="spectrogram", opts=dict(**FRONT), lens="fixed", nutt=1000, secs=10.0, pcm16=True),
     "mfcc13_dither1_1000x10s": dict(kind="mfcc", opts=dict(B=23, C=13, Q=22.0, lof=20.0, hif=8000.0, **{**FRONT, "dither": 1.0}), lens="fixed", nutt=1000, secs=10.0),
+    "mfcc13_8kHz_1000x10s": dict(kind="mfcc", opts=dict(sr=8000.0, B=23, C=13, Q=22.0, lof=20.0, hif=4000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=8000.0),
     "plp13_1000x10s": dict(kind="plp", opts=dict(B=23, C=13, Q=22.0, compress=1.0 / 3.0, cep_scale=1.0, lof=20.0, hif=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
 }
 HEADLINE = "spectrogram_1000x10s"
@@ -42,7 +43,7 @@ HEADLINE = "spectrogram_1000x10s"
 
 def lengths(w, rank):
     if w["lens"] == "fixed":
-        return np.full(w["nutt"], int(w["secs"] * SR), dtype=np.uint64)
+        return np.full(w["nutt"], int(w["secs"] * w.get("sr", SR)), dtype=np.uint64)
     rng = np.random.default_rng(0x5EED2026 + rank)
     return rng.integers(16000, 480001, size=w["nutt"]).astype(np.uint64)     # 1-30 s, SURVEY.md 8(d) config 3
 
@@ -78,7 +79,7 @@ class Work:
         if self.pcm16:
             self.X = self.X.round().clamp(-32767, 32767).to(torch.int16)
         self.Y = torch.zeros(self.batch.total_out, device=device, dtype=torch.float32)
-        self.audio_s = float(self.batch.total_samples) / SR
+        self.audio_s = float(self.batch.total_samples) / w.get("sr", SR)
         # algorithmic bytes per launch: read every sample once, write every feature once
         self.bytes = (2.0 if self.pcm16 else 4.0) * self.batch.total_samples + 4.0 * self.batch.total_out
 

@@ -1,5 +1,6 @@
 // fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, even frame shift;
-// dithered frames have their own instantiations).  Everything else runs on generic_kernels.hip.
+// dithered frames have their own instantiations) and, as zero-padded 512-point frames of which the even bins are kept,
+// 256-point frames (129..256 samples).  Everything else runs on generic_kernels.hip.
 //
 // Unit of work: a QUAD = 4 consecutive frames of one utterance, owned by ONE 64-lane wavefront
 // (16 lanes per frame).  A 256-thread workgroup takes a tile of 16 consecutive frames, one quad per wave.
@@ -39,6 +40,7 @@ struct FastTables {
     float *d_mat2;     // mfcc: lifter-scaled DCT matrix [Bp4][Cp]; plp: IDFT bases [K4][16]
     float *d_aux;      // plp: eql[B] | lift[C]
     int nz;            // ceil(L / 32): rows of 32 samples that hold data
+    int bshift, F;     // 256-point plans: bshift 1, F = 129 bins (the even bins of the 512-point transform); else 0, 257
     int kind, B, C, P, D, MP, Cp, K2, ntile_m, ntile_c;
     int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES], mel_first[MAX_MTILES], mel_cnt[MAX_MTILES];
 };
@@ -53,7 +55,7 @@ constexpr int TILE_SPEC = 64;  // frames per workgroup, spectrogram: 4 sub-tiles
 constexpr int SUB = 16;                 // frames per sub-tile
 constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
 constexpr int TR_WAVE_C = 2048;         // floats of a wave's slice when the transposition image is complex (spectrogram kernel)
-constexpr int NFFT = 512, NC = 256, FB = 257;
+constexpr int NFFT = 512, NC = 256;
 constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 8 * 16 * 2;
 constexpr int TR_WAVE = 1032;           // floats of a wave's LDS slice: 4 frames x 16 x 16 reals (transposition image of the real, then the
                                         // imaginary parts), 4 x 257 outputs; four slices = the 16 x 258 power tile
@@ -69,6 +71,8 @@ struct FastParams {
     uint32_t ntiles;
     int L, stp, D, span, ws;            // span: floats of a quad's audio, rounded up to 64; ws: floats of a wave's LDS slice (>= span, TR_WAVE)
     int snip_edges, dc0, want_pre, want_post;
+    int bshift;                         // 0: 512-point frames; 1: 256-point frames (129..256 samples) run as zero-padded 512-point
+                                        // frames -- X256[k] = X512[2k] exactly -- and only the even bins are handed on
     float preemph;                      // 0 when pre-emphasis is off
     int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
     float dither;
@@ -577,39 +581,40 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             // The quad's 4 x 257 outputs are contiguous in Y: they are put in order in the slice behind the parked audio and
             // leave as 16-byte stores, 1 KB of whole cache lines per instruction -- the write path to HBM is bound by
             // requests in flight, and dword stores of 64-byte runs need eight times as many for the same bytes.
-            float *st = s_aud + p.span + f * FB;
+            // 256-point plans keep the even bins only (bshift = 1): bin k of the 512-point transform goes to column k >> 1.
+            const int sh = p.bshift, D = p.D;
+            const bool live = (k2 & sh) == 0;
+            float *st = s_aud + p.span + f * D;
             {
                 const f2 l = spec_log2((k2 == 0) ? 4.0f * rawe : pa[0], pb[0]);
-                st[k2] = l.x;
-                if (k2 > 0) { st[NC - k2] = l.y; }
-                if (k2 == 1) { st[NC] = l.y; }                                                  // bin 256 := bin 255
+                if (live) { st[k2 >> sh] = l.x; }
+                if (live && k2 > 0) { st[(NC - k2) >> sh] = l.y; }
+                if (k2 == (1 << sh)) { st[NC >> sh] = l.y; }                                    // last bin := the one before (c/kaldi_spectrogram.c:245-247)
             }
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1)
             {
                 const f2 l = spec_log2(pa[k1], pb[k1]);
-                st[k2 + 16 * k1] = l.x;
-                st[NC - k2 - 16 * k1] = l.y;
+                if (live) { st[(k2 + 16 * k1) >> sh] = l.x; st[(NC - k2 - 16 * k1) >> sh] = l.y; }
             }
-            if (k2 == 0) { st[128] = spec_log(pa[8]); }
+            if (k2 == 0) { st[128 >> sh] = spec_log(pa[8]); }
             wave_sync();
             const float *so = s_aud + p.span;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(p.Y + ((p.ablate & 8) ? (unsigned long long)((blockIdx.x & 31u) * TILE_SPEC + (fq & (TILE_SPEC - 1))) * FB
-                                               : utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * FB)), 0, (p.ablate & 1) ? 0 : nfr * FB * 4, BUF_FLAGS);
+                (void *)(p.Y + ((p.ablate & 8) ? (unsigned long long)((blockIdx.x & 31u) * TILE_SPEC + (fq & (TILE_SPEC - 1))) * D
+                                               : utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * D)), 0, (p.ablate & 1) ? 0 : nfr * D * 4, BUF_FLAGS);
             if (nfr == QF)
             {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
+                // QF * D floats = D chunks of 16 bytes (257: four full instructions and one lane; 129: two and one lane)
+                for (int c = lane; c < D; c += 64)
                 {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(so + 4 * lane + 256 * i);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane * 16, i * 1024, 0);
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(so + 4 * c);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, c * 16, 0, 0);
                 }
-                if (lane == 0) { __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(so + 1024), ry, 0, 4096, 0); }
             }
-            else                                                            // the last quad of an utterance: 257, 514 or 771 floats
+            else                                                            // the last quad of an utterance: 1..3 frames
             {
-                const int n = nfr * FB;
+                const int n = nfr * D;
                 for (int i = lane; i < n; i += 64) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, so[i]), ry, i * 4, 0, 0); }
             }
         }
@@ -717,14 +722,22 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
 #pragma unroll
             for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
         }
-        float *pd = pr + (NC - 112 - k2);
-#pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1)
+        // 256-point plans (bshift = 1): only the even bins exist, bin k of the 512-point transform is column k >> 1
+        const int sh = p.bshift;
+        if ((k2 & sh) == 0)
         {
-            pr[k2 + 16 * k1] = pa[k1];
-            pd[16 * (7 - k1)] = pb[k1];
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1)
+            {
+                pr[(k2 + 16 * k1) >> sh] = pa[k1];
+                pr[(NC - k2 - 16 * k1) >> sh] = pb[k1];
+            }
         }
-        if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }
+        if (k2 == 0)
+        {
+            pr[128 >> sh] = pa[8]; s_e[fq + f] = rawe;
+            for (int c = (NC >> sh) + 1; c < (sh ? 132 : PP); ++c) { pr[c] = 0.0f; }       // columns a padded k-loop may touch (zero weights)
+        }
     }
     __syncthreads();
 
@@ -874,6 +887,10 @@ kernel_fn kernel_for(int nz, int kind, bool dither, bool pcm)
 {
     switch (nz)
     {
+        case 5: return kernel_for_nz<5>(kind, dither, pcm);
+        case 6: return kernel_for_nz<6>(kind, dither, pcm);
+        case 7: return kernel_for_nz<7>(kind, dither, pcm);
+        case 8: return kernel_for_nz<8>(kind, dither, pcm);
         case 9: return kernel_for_nz<9>(kind, dither, pcm);
         case 10: return kernel_for_nz<10>(kind, dither, pcm);
         case 11: return kernel_for_nz<11>(kind, dither, pcm);
@@ -891,11 +908,13 @@ int mel_pitch(int cols) { return 32 * ((cols + 31) / 32) + 2; }              // 
 
 bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
 {
-    if (o.dtype != SPEECH_F32 || nfft != (size_t)NFFT) { return false; }
+    // 512-point frames (257..512 samples), and 256-point frames (129..256) as zero-padded 512-point ones
+    if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u)) { return false; }
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
-    if (stp < 2u || stp > 1024u || (stp & 1u) || L > (size_t)NFFT || L <= (size_t)NFFT / 2u) { return false; }
+    if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return false; }
+    const size_t FBp = nfft / 2u + 1u;
     const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 63u) & ~(size_t)63;
-    if (o.kind == SPEECH_SPECTROGRAM) { return (TAB_FLOATS + (NT / 64) * std::max(span + QF * FB, (size_t)TR_WAVE_C)) * sizeof(float) <= 64u * 1024u; }
+    if (o.kind == SPEECH_SPECTROGRAM) { return (TAB_FLOATS + (NT / 64) * std::max(span + QF * FBp, (size_t)TR_WAVE_C)) * sizeof(float) <= 64u * 1024u; }
     if (o.B < 2u || o.B > 94u) { return false; }
     size_t D = o.B + (o.use_energy ? 1u : 0u), cols = 0;
     if (o.kind == SPEECH_MFCC) { if (o.C > 96u) { return false; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
@@ -923,7 +942,7 @@ static hipError_t upload_floats(const std::vector<float> &h, float **d)
 
 // Returns nullptr with *err empty when the option set turns out not to fit the tuned kernels (the plan then uses the
 // generic kernels), nullptr with a message on a real failure.
-FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, size_t B, size_t C, size_t P, const std::vector<float> &win,
+FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nfft, size_t B, size_t C, size_t P, const std::vector<float> &win,
                                const std::vector<float> &f2b, const std::vector<int> &beg, const std::vector<int> &num, const std::vector<float> &dct,
                                const std::vector<float> &lift, const std::vector<float> &eql, const std::vector<float> &idft, std::string *err)
 {
@@ -942,7 +961,9 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, s
     t->d_tab = t->d_melw = t->d_mat2 = t->d_aux = nullptr;
     t->nz = (int)((L + 31u) / 32u); t->kind = o.kind;
     t->B = t->C = t->P = t->MP = t->Cp = t->K2 = t->ntile_m = t->ntile_c = 0;
-    t->D = FB;
+    t->bshift = (nfft == (size_t)NFFT / 2u) ? 1 : 0; t->F = (int)(nfft / 2u + 1u);
+    t->D = t->F;
+    const int klim = t->bshift ? 132 : PP;                                   // power-tile columns a k-loop may touch
     std::vector<float> melw, mat2, aux;
     if (o.kind != SPEECH_SPECTROGRAM)
     {
@@ -959,7 +980,7 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t, s
             int kmin = 1 << 30, kmax = -1;
             for (int m = i; m < j; ++m) { const int b = src_of(m); if (num[b] > 0) { kmin = std::min(kmin, beg[b]); kmax = std::max(kmax, beg[b] + num[b]); } }
             ks = 0; kb = 0;
-            if (kmax > kmin) { ks = (((kmax - kmin + 3) / 4) + 3) & ~3; kb = kmin; if (kb + 4 * ks > PP) { kb = PP - 4 * ks; } }
+            if (kmax > kmin) { ks = (((kmax - kmin + 3) / 4) + 3) & ~3; kb = kmin; if (kb + 4 * ks > klim) { kb = klim - 4 * ks; } }
         };
         // Columns are dealt to tiles of at most 16 so that the LONGEST k-loop is as short as possible: with equal column
         // counts the high tiles (wide triangles) take 2-3x the k-steps of the low ones and their waves finish last.
@@ -1037,7 +1058,8 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.X = fp.X; p.X16 = fp.X16; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     p.span = ((QF - 1) * fp.stp + 32 * t->nz + 63) & ~63;     // whole 64-lane load instructions fit the slice
-    p.ws = (t->kind == SPEECH_SPECTROGRAM) ? std::max(p.span + QF * FB, TR_WAVE_C) : std::max(p.span, TR_WAVE);   // spectrogram: + the quad's output, staged behind the parked audio
+    p.bshift = t->bshift;
+    p.ws = (t->kind == SPEECH_SPECTROGRAM) ? std::max(p.span + QF * t->F, TR_WAVE_C) : std::max(p.span, TR_WAVE);   // spectrogram: + the quad's output, staged behind the parked audio
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.do_dither = fp.do_dither; p.dither = fp.dither; p.seed = fp.seed;
