@@ -221,6 +221,50 @@ def test_large_batch_config2_properties():
     assert ok, msg
 
 
+@pytest.mark.parametrize("kind,nutt", [("mfcc", 7000), ("spectrogram", 4400)])
+def test_packed_arrays_beyond_4_GiB(kind, nutt):
+    """maximum sizes: a batch whose packed audio (mfcc: 4.5 GB) or packed features (spectrogram: 4.5 GB) is larger than
+    32-bit byte offsets reach.  Utterances cycle through 7 distinct signals; the LAST utterance of each kind of signal
+    must equal the first one bit for bit, and the last utterance must match the oracle."""
+    import torch
+    nd = 7
+    xs = [signals.utterance(160000, 800 + i) for i in range(nd)]
+    plan = api.Plan(kind)
+    b = api.Batch(plan, [160000] * nutt)
+    assert max(b.total_samples, b.total_out) * 4 > 2 ** 32
+    base = torch.from_numpy(np.concatenate(xs)).cuda()
+    X = base.repeat((nutt + nd - 1) // nd)[:b.total_samples].contiguous()
+    del base
+    Y = torch.zeros(b.total_out, device="cuda")
+    b.run(X, Y)
+    torch.cuda.synchronize()
+    Yv = Y.view(nutt, 998, plan.D)
+    for i in range(nd):
+        last = i + nd * ((nutt - 1 - i) // nd)
+        assert bool((Yv[last] == Yv[i]).all()), (i, last)
+    ok, msg = _parity(kind, {}, xs[(nutt - 1) % nd], Yv[nutt - 1].cpu().numpy())
+    assert ok, msg
+    b.close(); plan.close()
+    del X, Y, Yv
+    torch.cuda.empty_cache()
+
+
+def test_one_hour_utterance_through_the_dropin_entry():
+    """one utterance of 57.6 M samples (1 h at 16 kHz, 230 MB) through kaldi_mfcc_s with host pointers: 359 998 frames.
+    The audio is a 10 s signal repeated, and 10 s is a whole number of frame shifts, so frames 1000 k .. 1000 k + 997
+    repeat frames 0 .. 997 exactly; those match the oracle on the 10 s signal."""
+    x10 = signals.utterance(160000, 999)
+    x = np.tile(x10, 360)
+    got = api.kaldi_mfcc(x, snip_edges=1)
+    assert got.shape == (359998, 13)
+    for k in (1, 7, 180, 359):
+        assert np.array_equal(got[1000 * k:1000 * k + 998], got[:998]), k
+    ok, msg = _parity("mfcc", {}, x10, got[:998])
+    assert ok, msg
+    # the frames that straddle a seam exist and are finite
+    assert np.isfinite(got).all()
+
+
 def test_dither_is_seeded_and_has_the_right_scale():
     import torch
     x = np.zeros(16000, dtype=np.float32)
