@@ -265,6 +265,43 @@ def test_one_hour_utterance_through_the_dropin_entry():
     assert np.isfinite(got).all()
 
 
+def test_dropin_calls_from_many_threads():
+    """the ten drop-in symbols are re-entrant and thread-safe (the reference is not: FFTW planning): eight
+    threads call different functions with different options at once (ctypes drops the GIL), more option sets than the
+    plan cache holds, and every result equals the same call made alone"""
+    import threading
+    jobs = []
+    for i in range(24):
+        x = signals.utterance(3000 + 977 * i, 500 + i)
+        if i % 4 == 0:
+            jobs.append((api.kaldi_mfcc, x, dict(B=23 + i, C=13, snip_edges=i % 2)))
+        elif i % 4 == 1:
+            jobs.append((api.kaldi_fbank, x, dict(B=20 + i, use_energy=i % 2)))
+        elif i % 4 == 2:
+            jobs.append((api.kaldi_spectrogram, x.astype(np.float64), dict(frame_length=20.0 + i)))
+        else:
+            jobs.append((api.kaldi_plp, x, dict(B=23 + i, C=13)))
+    want = [f(x, **kw) for f, x, kw in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(t):
+        try:
+            for rep in range(3):
+                for j in range(t, len(jobs), 8):
+                    f, x, kw = jobs[j]
+                    got[j] = f(x, **kw)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for j, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), j
+
+
 def test_dither_is_seeded_and_has_the_right_scale():
     import torch
     x = np.zeros(16000, dtype=np.float32)
