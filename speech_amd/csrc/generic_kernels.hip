@@ -32,14 +32,14 @@ template <> struct M<double> {
 constexpr int NT = 256;
 
 // Sum over the workgroup; every thread returns the same value.  `red` holds NT elements.
-template <typename T>
+template <typename T, int NTH>
 __device__ __forceinline__ T block_sum(T v, T *red)
 {
     const int tid = threadIdx.x;
     __syncthreads();
     red[tid] = v;
     __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1)
+    for (int s = NTH / 2; s > 0; s >>= 1)
     {
         if (tid < s) { red[tid] += red[tid + s]; }
         __syncthreads();
@@ -54,8 +54,10 @@ __device__ __forceinline__ T floor_log(T v)
     return (v < eps) ? M<T>::log(eps) : M<T>::log(v);
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T> p)
+// NTH threads per workgroup: 256 for long transforms; 64 (one wave: its barriers cost next to nothing, and four times as
+// many frames are in flight per CU) for nfft <= 1024 -- 1.4-1.9x faster there (tools/generic_time.py).
+template <typename T, int NTH>
+__global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T> p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
     T *re = reinterpret_cast<T *>(smem_raw);
     T *im = re + nfft;
     T *red = im + nfft;            // NT
-    T *mel = red + NT;             // B
+    T *mel = red + NT;             // B (red is sized for the larger workgroup)
     T *dup = mel + B;              // B+2
     T *ac = dup + (B + 2);         // P+1
     T *lpc = ac + (P + 1);         // P+1
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         // frame start: c/kaldi_mfcc.c:81-82,216-240
         const long long start = p.snip_edges ? w * p.stp : (long long)(p.stp / 2) - (long long)(L / 2) + w * p.stp;
         __syncthreads();
-        for (int l = tid; l < nfft; l += NT)
+        for (int l = tid; l < nfft; l += NTH)
         {
             T v = (T)0;
             if (l < L)
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         {
             // Gaussian pairs by Box-Muller as c/kaldi_mfcc.c:243-262, from a counter-based hash (speech_internal.hpp)
             const unsigned long long key = mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) + (unsigned long long)w * DITHER_FRAME_MUL;
-            for (int i = tid; 2 * i < L; i += NT)
+            for (int i = tid; 2 * i < L; i += NTH)
             {
                 T g0, g1;
                 dither_pair(mix64(key + (unsigned long long)i), p.dither, g0, g1);
@@ -115,27 +117,27 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         if (p.want_pre && p.pre_before_dc)                 // kaldi_mfcc_d only: c/kaldi_mfcc.c:576-582
         {
             T s = (T)0;
-            for (int l = tid; l < L; l += NT) { s += re[l] * re[l]; }
-            rawe = block_sum(s, red);
+            for (int l = tid; l < L; l += NTH) { s += re[l] * re[l]; }
+            rawe = block_sum<T, NTH>(s, red);
             if (rawe < eps) { rawe = eps; }
         }
         if (p.dc0)                                         // c/kaldi_mfcc.c:265-271
         {
             T s = (T)0;
-            for (int l = tid; l < L; l += NT) { s += re[l]; }
-            const T mn = block_sum(s, red) / (T)L;
-            for (int l = tid; l < L; l += NT) { re[l] -= mn; }
+            for (int l = tid; l < L; l += NTH) { s += re[l]; }
+            const T mn = block_sum<T, NTH>(s, red) / (T)L;
+            for (int l = tid; l < L; l += NTH) { re[l] -= mn; }
             __syncthreads();
         }
         if (p.want_pre && !p.pre_before_dc)                // c/kaldi_mfcc.c:274-279
         {
             T s = (T)0;
-            for (int l = tid; l < L; l += NT) { s += re[l] * re[l]; }
-            rawe = block_sum(s, red);
+            for (int l = tid; l < L; l += NTH) { s += re[l] * re[l]; }
+            rawe = block_sum<T, NTH>(s, red);
             if (rawe < eps) { rawe = eps; }
         }
         // pre-emphasis (closed form of the backwards in-place loop, c/kaldi_mfcc.c:282-288) and window (:291)
-        for (int l = tid; l < nfft; l += NT)
+        for (int l = tid; l < nfft; l += NTH)
         {
             T v = (T)0;
             if (l < L)
@@ -150,19 +152,19 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         if (p.want_post)                                   // c/kaldi_mfcc.c:295-301
         {
             T s = (T)0;
-            for (int l = tid; l < L; l += NT) { s += im[l] * im[l]; }
-            rawe = block_sum(s, red);
+            for (int l = tid; l < L; l += NTH) { s += im[l] * im[l]; }
+            rawe = block_sum<T, NTH>(s, red);
             if (rawe < eps) { rawe = eps; }
         }
         // FFT (replaces the FFTW R2HC call, c/kaldi_mfcc.c:304): radix-2 DIT on the zero-padded frame
-        for (int l = tid; l < nfft; l += NT) { re[__brev((unsigned)l) >> (32 - p.log2n)] = im[l]; }
+        for (int l = tid; l < nfft; l += NTH) { re[__brev((unsigned)l) >> (32 - p.log2n)] = im[l]; }
         __syncthreads();
-        for (int l = tid; l < nfft; l += NT) { im[l] = (T)0; }
+        for (int l = tid; l < nfft; l += NTH) { im[l] = (T)0; }
         __syncthreads();
         for (int half = 1; half < nfft; half <<= 1)
         {
             const int tstep = nfft / (2 * half);
-            for (int i = tid; i < nfft / 2; i += NT)
+            for (int i = tid; i < nfft / 2; i += NTH)
             {
                 const int k = i & (half - 1);
                 const int a = ((i - k) << 1) + k, b = a + half;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
             __syncthreads();
         }
         // power, c/kaldi_mfcc.c:307-310 (im[0] = im[nfft/2] = 0 for a real input up to rounding; the reference never adds them)
-        for (int k = tid; k < F; k += NT)
+        for (int k = tid; k < F; k += NTH)
         {
             T pw = re[k] * re[k];
             if (k > 0 && k < F - 1) { pw += im[k] * im[k]; }
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         if (p.kind == SPEECH_SPECTROGRAM)
         {
             // c/kaldi_spectrogram.c:236-251
-            for (int k = tid; k < F; k += NT)
+            for (int k = tid; k < F; k += NTH)
             {
                 const T v = (k == 0) ? rawe : ((k == F - 1) ? re[F - 2] : re[k]);
                 y[k] = floor_log(v);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         }
 
         // sparse mel sums, c/kaldi_mfcc.c:313-320 / c/kaldi_fbank.c:312-345
-        for (int b = tid; b < B; b += NT)
+        for (int b = tid; b < B; b += NTH)
         {
             const T *wgt = p.f2b + p.mel_off[b];
             const int beg = p.mel_beg[b], num = p.mel_num[b];
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         if (p.kind == SPEECH_FBANK)
         {
             const int eo = p.use_energy ? 1 : 0;
-            for (int b = tid; b < B; b += NT)
+            for (int b = tid; b < B; b += NTH)
             {
                 const int src = (b == B - 1 && B >= 2) ? B - 2 : b;        // c/kaldi_fbank.c:350
                 const T v = mel[src];
@@ -228,9 +230,9 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
 
         if (p.kind == SPEECH_MFCC)
         {
-            for (int b = tid; b < B; b += NT) { mel[b] = floor_log(mel[b]); }   // c/kaldi_mfcc.c:318
+            for (int b = tid; b < B; b += NTH) { mel[b] = floor_log(mel[b]); }   // c/kaldi_mfcc.c:318
             __syncthreads();
-            for (int c = tid; c < C; c += NT)
+            for (int c = tid; c < C; c += NTH)
             {
                 const int cc = (c == C - 1 && C >= 2) ? C - 2 : c;         // c/kaldi_mfcc.c:333
                 const T *d = p.dct + (size_t)cc * B;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
         }
 
         // PLP tail
-        for (int j = tid; j < B + 2; j += NT)
+        for (int j = tid; j < B + 2; j += NTH)
         {
             const int b = (j == 0) ? 0 : ((j == B + 1) ? B - 1 : j - 1);
             const T v = mel[b] * p.eql[b];
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
             dup[j] = cv;
         }
         __syncthreads();
-        for (int i = tid; i <= P; i += NT)
+        for (int i = tid; i <= P; i += NTH)
         {
             const T *row = p.idft + (size_t)i * (B + 2);
             T acc = (T)0;
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(NT) void generic_frames_kernel(const FrameParams<T>
             sc0[0] = floor_log(E);
         }
         __syncthreads();
-        for (int k = tid; k < C; k += NT)
+        for (int k = tid; k < C; k += NTH)
         {
             const int kk = (k == C - 1 && C >= 2) ? C - 2 : k;
             T v = (kk == 0) ? sc0[0] : ((kk - 1 < P) ? cep[kk - 1] : (T)0);
@@ -305,11 +307,12 @@ hipError_t launch_generic(const FrameParams<T> &p, hipStream_t s)
     const size_t lds = generic_lds_bytes(p.nfft, p.B, p.C, p.P, sizeof(T));
     if (lds > 48 * 1024)   // opt in to large dynamic LDS on whichever device is current
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&generic_frames_kernel<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&generic_frames_kernel<T, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { return e; }
     }
-    hipLaunchKernelGGL(generic_frames_kernel<T>, dim3(p.ntiles), dim3(NT), lds, s, p);
+    if (p.nfft <= 1024) { hipLaunchKernelGGL((generic_frames_kernel<T, 64>), dim3(p.ntiles), dim3(64), lds, s, p); }
+    else { hipLaunchKernelGGL((generic_frames_kernel<T, NT>), dim3(p.ntiles), dim3(NT), lds, s, p); }
     return hipGetLastError();
 }
 
