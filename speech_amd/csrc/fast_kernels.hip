@@ -3,7 +3,8 @@
 // 256-point frames (129..256 samples).  Everything else runs on generic_kernels.hip.
 //
 // Unit of work: a QUAD = 4 consecutive frames of one utterance, owned by ONE 64-lane wavefront
-// (16 lanes per frame).  A 256-thread workgroup takes a tile of 16 consecutive frames, one quad per wave.
+// (16 lanes per frame).  Mel kinds: a 512-thread workgroup takes a tile of 32 consecutive frames, one quad per wave;
+// spectrogram: 256 threads walk a tile of 64 frames in four sub-tiles.
 //
 //   audio      the wave loads the quad's contiguous sample span ((4-1)*stp + L floats) with coalesced
 //              global loads into its private LDS slice; the overlapping frames are cut from LDS
@@ -50,7 +51,11 @@ namespace {
 
 constexpr int NT = 256;                 // threads per workgroup (4 waves)
 constexpr int QF = 4;                   // frames per wave (quad)
-constexpr int TILE = 16;                // frames per workgroup, mel kinds
+constexpr int MW = 8;                   // waves per workgroup, mel kinds: with 32 frames the matrix-core phases have two row tiles
+                                        // per mel tile, i.e. a job for every wave, and half as many workgroup barriers per frame
+constexpr int NTM = 64 * MW;            // threads per workgroup, mel kinds
+constexpr int TILE = QF * MW;           // frames per workgroup, mel kinds
+constexpr int RT = TILE / 16;           // 16-frame row tiles of the MFMA contractions
 constexpr int TILE_SPEC = 64;  // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
 constexpr int SUB = 16;                 // frames per sub-tile
 constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
@@ -59,7 +64,7 @@ constexpr int NFFT = 512, NC = 256;
 constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 8 * 16 * 2;
 constexpr int TR_WAVE = 1032;           // floats of a wave's LDS slice: 4 frames x 16 x 16 reals (transposition image of the real, then the
                                         // imaginary parts), 4 x 257 outputs; four slices = the 16 x 258 power tile
-constexpr int PP = 258;                 // pitch of the 16 x 257 power tile (= 2 mod 32: conflict-free MFMA operand reads)
+constexpr int PP = 258;                 // pitch of the TILE x 257 power tile (= 2 mod 32: conflict-free MFMA operand reads)
 constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
 struct FastParams {
@@ -670,7 +675,7 @@ __device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const float *brow
 // fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
 // Levinson-Durbin and the cepstral recursion stay in registers).
 template <int NZ, int KIND, int P, bool DITHER>
-__global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
+__global__ __launch_bounds__(NTM) void fast_mel_kernel(const FastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -678,13 +683,15 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     float *s_tab = smem;
     float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
-    // after the FFTs the four slices are dead and hold: 16 x PP power tile | frame energies | output tile | mel tile | autocorrelations
+    // after the FFTs the slices are dead and hold the TILE x PP power tile
     float *s_pow = smem + TAB_FLOATS;
-    float *s_e = smem + TAB_FLOATS + (NT / 64) * p.ws;                      // private region behind the slices
-    float *s_out = s_e + 16;
-    float *s_mel = s_out + ((16 * p.D + 3) & ~3);
-    float *s_ac = s_mel + 16 * p.MP;
-    for (int i = tid; i < TAB_FLOATS; i += NT) { s_tab[i] = p.tab[i]; }
+    // private region behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile.  The mfcc / plp output
+    // tile (and plp's autocorrelations) are written after the power tile is dead and reuse its place.
+    float *s_e = smem + TAB_FLOATS + MW * p.ws;
+    float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILE : s_pow;
+    float *s_mel = s_e + TILE;
+    float *s_ac = s_out + ((TILE * p.D + 3) & ~3);
+    for (int i = tid; i < TAB_FLOATS; i += NTM) { s_tab[i] = p.tab[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     __syncthreads();                                                        // every wave is done with its slice
     if (p.ablate & 4) { if (pa[0] + pb[3] + rawe == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
-    // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> 16 x 257 tile, column 257 zero
+    // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILE x 257 tile, column 257 zero
     {
         float *pr = s_pow + (fq + f) * PP;
         if (p.amp)
@@ -744,15 +751,16 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
     const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
     const int fr0 = (lane >> 4) * 4, col = lane & 15;
-    for (int t = wv; t < p.ntile_m; t += NT / 64)
+    for (int job = wv; job < RT * p.ntile_m; job += MW)
     {
-        const f32x4 acc = mfma_tile4(s_pow + col * PP + p.mel_kbeg[t] + (lane >> 4), p.melw + p.mel_woff[t] + lane, p.mel_ksteps[t]);
+        const int t = job / RT, rt = job - t * RT;                          // mel tile, 16-frame row tile
+        const f32x4 acc = mfma_tile4(s_pow + (16 * rt + col) * PP + p.mel_kbeg[t] + (lane >> 4), p.melw + p.mel_woff[t] + lane, p.mel_ksteps[t]);
         const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
         const bool live = col < p.mel_cnt[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
-            const int fr = fr0 + r;
+            const int fr = 16 * rt + fr0 + r;
             const float v = acc[r];
             if (KIND == SPEECH_FBANK)
             {
@@ -776,21 +784,22 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
             }
         }
     }
-    if (KIND == SPEECH_FBANK && eo && tid < 16) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
-    if (KIND == SPEECH_MFCC && tid < 64) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
+    if (KIND == SPEECH_FBANK && eo && tid < TILE) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
+    if (KIND == SPEECH_MFCC && tid < 4 * TILE) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
     __syncthreads();
 
     if (KIND == SPEECH_MFCC)
     {
         // DCT-II x lifter as a second contraction (c/kaldi_mfcc.c:323-333); the last-cepstrum quirk is a duplicated column
-        for (int t = wv; t < p.ntile_c; t += NT / 64)
+        for (int job = wv; job < RT * p.ntile_c; job += MW)
         {
-            const f32x4 acc = mfma_tile(s_mel + col * p.MP + (lane >> 4), p.mat2 + (lane >> 4) * p.Cp + 16 * t + col, 4 * p.Cp, p.K2 >> 2);
+            const int t = job / RT, rt = job - t * RT;
+            const f32x4 acc = mfma_tile(s_mel + (16 * rt + col) * p.MP + (lane >> 4), p.mat2 + (lane >> 4) * p.Cp + 16 * t + col, 4 * p.Cp, p.K2 >> 2);
             const int c = 16 * t + col;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
             {
-                const int fr = fr0 + r;
+                const int fr = 16 * rt + fr0 + r;
                 if (c < p.C) { s_out[fr * p.C + c] = (p.use_energy && c == 0) ? pos_log(s_e[fr]) : acc[r]; }
             }
         }
@@ -798,15 +807,15 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     }
     if (KIND == SPEECH_PLP)
     {
-        // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile, wave 0
-        if (wv == 0)
+        // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames
+        if (wv < RT)
         {
-            const f32x4 acc = mfma_tile(s_mel + col * p.MP + (lane >> 4), p.mat2 + lane, 64, p.K2 >> 2);
+            const f32x4 acc = mfma_tile(s_mel + (16 * wv + col) * p.MP + (lane >> 4), p.mat2 + lane, 64, p.K2 >> 2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s_ac[(fr0 + r) * 17 + col] = acc[r]; }
+            for (int r = 0; r < 4; ++r) { s_ac[(16 * wv + fr0 + r) * 17 + col] = acc[r]; }
         }
         __syncthreads();
-        if (tid < 16)
+        if (tid < TILE)
         {
             // one lane per frame: Levinson-Durbin with Kaldi's 1 - k^2 >= 1e-5 guard, LPC -> cepstrum, lifter
             // (reference intent c/kaldi_plp.c:206,380-403)
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(NT) void fast_mel_kernel(const FastParams p)
     // the tile's nframes x D outputs are one contiguous run of Y
     float *y = p.Y + utt.y_off + (unsigned long long)tile.frame0 * (unsigned long long)p.D;
     const int nout = (int)tile.nframes * p.D;
-    for (int i = tid; i < nout; i += NT) { y[i] = s_out[i]; }
+    for (int i = tid; i < nout; i += NTM) { y[i] = s_out[i]; }
 }
 
 typedef void (*kernel_fn)(const FastParams);
@@ -924,9 +933,10 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
         if (P != 12u) { return false; }                                     // the in-register Levinson-Durbin is built for order 12
         D = o.C; cols = (o.B + 2u + 3u) & ~(size_t)3;
     }
-    // the power / output / mel / autocorrelation tiles reuse the four wave slices
-    const size_t extra = 16u + ((16u * D + 3u) & ~(size_t)3) + 16u * (size_t)mel_pitch((int)cols) + 16u * 17u;
-    return (TAB_FLOATS + (NT / 64) * std::max(span, (size_t)TR_WAVE) + extra) * sizeof(float) <= 64u * 1024u;
+    // the power tile (and the mfcc / plp output and autocorrelation tiles) reuse the wave slices
+    const size_t extra = (size_t)TILE + (o.kind == SPEECH_FBANK ? (((size_t)TILE * D + 3u) & ~(size_t)3) : (size_t)TILE * (size_t)mel_pitch((int)cols));
+    if (((size_t)TILE * D + 3u + (size_t)TILE * 17u) > (size_t)MW * TR_WAVE) { return false; }
+    return (TAB_FLOATS + MW * std::max(span, (size_t)TR_WAVE) + extra) * sizeof(float) <= 64u * 1024u;
 }
 
 int fast_tile_frames(const speech_opts &o) { return o.kind == SPEECH_SPECTROGRAM ? TILE_SPEC : TILE; }
@@ -1069,8 +1079,9 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;
     p.amp = fp.amp; p.lg = fp.lg; p.use_energy = fp.use_energy; p.compress_mode = fp.compress_mode; p.compress = fp.compress;
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; p.mel_first[i] = t->mel_first[i]; p.mel_cnt[i] = t->mel_cnt[i]; }
-    size_t lds = (size_t)(TAB_FLOATS + (NT / 64) * p.ws) * sizeof(float);
-    if (t->kind != SPEECH_SPECTROGRAM) { lds += (size_t)(16 + ((16 * t->D + 3) & ~3) + 16 * t->MP + 16 * 17) * sizeof(float); }
+    const bool mel = t->kind != SPEECH_SPECTROGRAM;
+    size_t lds = (size_t)(TAB_FLOATS + (mel ? MW : NT / 64) * p.ws) * sizeof(float);
+    if (mel) { lds += (size_t)(TILE + (t->kind == SPEECH_FBANK ? ((TILE * t->D + 3) & ~3) : TILE * t->MP)) * sizeof(float); }
     kernel_fn k = kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
@@ -1079,7 +1090,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
         if (e != hipSuccess) { return e; }
     }
     if (ev0) { e = hipEventRecord(ev0, s); if (e != hipSuccess) { return e; } }
-    hipLaunchKernelGGL(k, dim3(fp.ntiles), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL(k, dim3(fp.ntiles), dim3(mel ? NTM : NT), lds, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) { return e; }
     if (ev1) { e = hipEventRecord(ev1, s); }
