@@ -649,19 +649,22 @@ __device__ __forceinline__ f32x4 mfma_tile(const float *arow, const float *brow,
 // The mel contraction: `ksteps` is a multiple of 4 (host pads with zero weights).  Operands of the next four k-steps are
 // loaded while the current four MFMAs run, so the L1/L2 latency of the weights is paid once per tile instead of per step
 // (8 more VGPRs; fetching deeper costs occupancy and measured slower).
-__device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const float *brow, const int ksteps)
+__device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const __amdgpu_buffer_rsrc_t rb, const int bvoff, const int ksteps)
 {
+    // the weights come through a raw buffer descriptor: the lane's byte offset stays in one VGPR and the k-step advances
+    // in an SGPR, so the loop spends no vector instructions on 64-bit addresses
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (ksteps <= 0) { return acc0; }
     float a[4], b[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { b[j] = brow[64 * j]; a[j] = arow[4 * j]; }
+    for (int j = 0; j < 4; ++j) { b[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, bvoff, 256 * j, 0)); a[j] = arow[4 * j]; }
     for (int s = 0; s < ksteps; s += 4)
     {
         const int sn = min(s + 4, ksteps - 4);                              // the last trip reloads its own block (harmless)
+        const float *an_p = arow + 4 * sn;
         float an[4], bn[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { bn[j] = brow[64 * (sn + j)]; an[j] = arow[4 * (sn + j)]; }
+        for (int j = 0; j < 4; ++j) { bn[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, bvoff, 256 * (sn + j), 0)); an[j] = an_p[4 * j]; }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
@@ -754,7 +757,8 @@ __global__ __launch_bounds__(NTM) void fast_mel_kernel(const FastParams p)
     for (int job = wv; job < RT * p.ntile_m; job += MW)
     {
         const int t = job / RT, rt = job - t * RT;                          // mel tile, 16-frame row tile
-        const f32x4 acc = mfma_tile4(s_pow + (16 * rt + col) * PP + p.mel_kbeg[t] + (lane >> 4), p.melw + p.mel_woff[t] + lane, p.mel_ksteps[t]);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * p.mel_ksteps[t], BUF_FLAGS);
+        const f32x4 acc = mfma_tile4(s_pow + (16 * rt + col) * PP + p.mel_kbeg[t] + (lane >> 4), rb, lane * 4, p.mel_ksteps[t]);
         const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
         const bool live = col < p.mel_cnt[t];
 #pragma unroll
