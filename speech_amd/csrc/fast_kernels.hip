@@ -33,7 +33,7 @@
 
 namespace speech {
 
-constexpr int MAX_MTILES = 8;            // mel tiles of up to 16 columns (B <= 94), balanced over the 4 waves; cepstral tiles of 16 (C <= 96)
+constexpr int MAX_MTILES = 8;            // mel tiles of up to 16 columns (B <= 128), balanced over the waves; cepstral tiles of 16 (C <= 96)
 
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[8][16] complex
@@ -928,7 +928,7 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
     const size_t FBp = nfft / 2u + 1u;
     const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 63u) & ~(size_t)63;
     if (o.kind == SPEECH_SPECTROGRAM) { return (TAB_FLOATS + (NT / 64) * std::max(span + QF * FBp, (size_t)TR_WAVE_C)) * sizeof(float) <= 64u * 1024u; }
-    if (o.B < 2u || o.B > 94u) { return false; }
+    if (o.B < 2u || o.B > 16u * MAX_MTILES) { return false; }                 // 128 mel bins
     size_t D = o.B + (o.use_energy ? 1u : 0u), cols = 0;
     if (o.kind == SPEECH_MFCC) { if (o.C > 96u) { return false; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
     if (o.kind == SPEECH_PLP)

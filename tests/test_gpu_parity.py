@@ -165,7 +165,7 @@ def test_tuned_and_generic_kernels_agree():
     import torch
     for kind, o in [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", {}), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {}),
                     ("spectrogram", dict(sr=8000.0)), ("mfcc", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(sr=8000.0, hif=4000.0, B=40, snip=0)),
-                    ("plp", dict(sr=8000.0, hif=4000.0))]:
+                    ("plp", dict(sr=8000.0, hif=4000.0)), ("fbank", dict(B=128, use_energy=1)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100, snip=0))]:
         x = signals.utterance(24000, 77, sr=o.get("sr", 16000.0))
         X = torch.from_numpy(x).cuda()
         outs = []
@@ -349,9 +349,10 @@ def test_which_plans_run_on_the_tuned_kernels():
     back to the generic kernels instead of failing"""
     tuned = [("mfcc", {}), ("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {}),
              ("fbank", dict(fl=20.0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("fbank", dict(B=23, hif=9000.0)), ("mfcc", dict(dither=0.5)),
-             ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("spectrogram", dict(sr=8000.0)), ("plp", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(fl=10.0, fs=5.0, B=40))]
+             ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("spectrogram", dict(sr=8000.0)), ("plp", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(fl=10.0, fs=5.0, B=40)),
+             ("fbank", dict(B=128)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100))]
     generic = [("mfcc", dict(sr=4000.0, hif=2000.0, B=15)), ("spectrogram", dict(sr=22050.0)), ("mfcc", dict(sr=16100.0)),
-               ("plp", dict(order=16)), ("fbank", dict(B=120)), ("mfcc", dict(fs=10.0625)), ("fbank", dict(B=1))]
+               ("plp", dict(order=16)), ("fbank", dict(B=129)), ("mfcc", dict(fs=10.0625)), ("fbank", dict(B=1))]
     for kind, o in tuned:
         assert api.Plan(kind, **o).tuned, (kind, o)
     for kind, o in generic:
