@@ -72,6 +72,16 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
     T *tmp = lpc + (P + 1);        // P+1
     T *cep = tmp + (P + 1);        // P+1
     T *sc0 = cep + (P + 1);        // 1
+    // one-wave workgroups (nfft <= 1024) keep the twiddles and the window in LDS: the radix-2 stages read a twiddle per
+    // butterfly, and from global memory each stage of each frame pays an L1/L2 latency for it
+    const T *twr = p.tw_re, *twi = p.tw_im, *wn = p.win;
+    if (NTH == 64 && sizeof(T) == 4)                                        // f64: the extra LDS costs more in occupancy than it saves
+    {
+        T *c_twr = sc0 + 4, *c_twi = c_twr + nfft / 2, *c_win = c_twi + nfft / 2;
+        for (int i = tid; i < nfft / 2; i += NTH) { c_twr[i] = p.tw_re[i]; c_twi[i] = p.tw_im[i]; }
+        for (int i = tid; i < L; i += NTH) { c_win[i] = p.win[i]; }
+        twr = c_twr; twi = c_twi; wn = c_win;
+    }
 
     const TileDesc tile = p.tiles[blockIdx.x];
     const UttDesc utt = p.utts[tile.utt];
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
             {
                 v = re[l];
                 if (p.do_preemph) { v -= p.preemph * ((l > 0) ? re[l - 1] : re[0]); }
-                v *= p.win[l];
+                v *= wn[l];
             }
             im[l] = v;
         }
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
             {
                 const int k = i & (half - 1);
                 const int a = ((i - k) << 1) + k, b = a + half;
-                const T c = p.tw_re[k * tstep], s = p.tw_im[k * tstep];
+                const T c = twr[k * tstep], s = twi[k * tstep];
                 const T tr = re[b] * c - im[b] * s;
                 const T ti = re[b] * s + im[b] * c;
                 const T ar = re[a], ai = im[a];
@@ -321,7 +331,8 @@ hipError_t launch_generic(const FrameParams<T> &p, hipStream_t s)
 size_t generic_lds_bytes(int nfft, int B, int C, int P, size_t elem)
 {
     (void)C;
-    const size_t n = (size_t)2 * nfft + NT + (size_t)B + (size_t)(B + 2) + (size_t)4 * (P + 1) + 4;
+    size_t n = (size_t)2 * nfft + NT + (size_t)B + (size_t)(B + 2) + (size_t)4 * (P + 1) + 4 + 4;
+    if (nfft <= 1024 && elem == 4) { n += (size_t)2 * nfft; }                             // twiddles and window cached by the one-wave workgroups
     return (n * elem + 15) & ~(size_t)15;
 }
 
