@@ -171,19 +171,47 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
         __syncthreads();
         for (int l = tid; l < nfft; l += NTH) { im[l] = (T)0; }
         __syncthreads();
-        for (int half = 1; half < nfft; half <<= 1)
+        // two radix-2 stages per pass over LDS: the four points a, b = a + half, c = a + 2 half, d = a + 3 half go through
+        // stage `half` (pairs a-b and c-d) and stage `2 half` (pairs a-c and b-d) in registers, with the same operations in
+        // the same order as two separate passes -- the results are bit-identical, for half the LDS traffic and barriers
+        int half = 1;
+        if (p.log2n & 1)
         {
-            const int tstep = nfft / (2 * half);
-            for (int i = tid; i < nfft / 2; i += NTH)
+            for (int i = tid; i < nfft / 2; i += NTH)                      // lone first stage: twiddle 1
             {
-                const int k = i & (half - 1);
-                const int a = ((i - k) << 1) + k, b = a + half;
-                const T c = twr[k * tstep], s = twi[k * tstep];
+                const int a = i << 1, b = a + 1;
+                const T c = twr[0], s = twi[0];
                 const T tr = re[b] * c - im[b] * s;
                 const T ti = re[b] * s + im[b] * c;
                 const T ar = re[a], ai = im[a];
                 re[b] = ar - tr; im[b] = ai - ti;
                 re[a] = ar + tr; im[a] = ai + ti;
+            }
+            __syncthreads();
+            half = 2;
+        }
+        for (; half < nfft; half <<= 2)
+        {
+            const int t1 = nfft / (2 * half), t2 = nfft / (4 * half);
+            for (int i = tid; i < nfft / 4; i += NTH)
+            {
+                const int k = i & (half - 1);
+                const int a = ((i - k) << 2) + k, b = a + half, c = b + half, d = c + half;
+                const T c1 = twr[k * t1], s1 = twi[k * t1];
+                const T c2 = twr[k * t2], s2 = twi[k * t2];
+                const T c3 = twr[(k + half) * t2], s3 = twi[(k + half) * t2];
+                T ar = re[a], ai = im[a], br = re[b], bi = im[b], cr = re[c], ci = im[c], dr = re[d], di = im[d];
+                // stage `half`
+                T tr = br * c1 - bi * s1, ti = br * s1 + bi * c1;
+                br = ar - tr; bi = ai - ti; ar = ar + tr; ai = ai + ti;
+                tr = dr * c1 - di * s1; ti = dr * s1 + di * c1;
+                dr = cr - tr; di = ci - ti; cr = cr + tr; ci = ci + ti;
+                // stage `2 half`
+                tr = cr * c2 - ci * s2; ti = cr * s2 + ci * c2;
+                cr = ar - tr; ci = ai - ti; ar = ar + tr; ai = ai + ti;
+                tr = dr * c3 - di * s3; ti = dr * s3 + di * c3;
+                dr = br - tr; di = bi - ti; br = br + tr; bi = bi + ti;
+                re[a] = ar; im[a] = ai; re[b] = br; im[b] = bi; re[c] = cr; im[c] = ci; re[d] = dr; im[d] = di;
             }
             __syncthreads();
         }
