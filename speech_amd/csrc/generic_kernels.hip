@@ -35,6 +35,14 @@ constexpr int NT = 256;
 template <typename T, int NTH>
 __device__ __forceinline__ T block_sum(T v, T *red)
 {
+    if (NTH == 64)
+    {
+        // one wave: the same pairing as the LDS tree below (lane i takes i + 32, then i + 16, ...), so the same bits,
+        // without LDS or barriers
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) { v += __shfl_xor(v, s, 64); }
+        return v;
+    }
     const int tid = threadIdx.x;
     __syncthreads();
     red[tid] = v;
