@@ -13,14 +13,14 @@
 //              reductions over the frame's 16 lanes (reference: c/kaldi_mfcc.c:265-301).
 //   FFT        512-point real FFT as a 256-point complex FFT of z[n] = x[2n] + i x[2n+1], n = n1 + 16 n2:
 //              lane n1 does a 16-point FFT over n2 in registers, multiplies by W256^(n1 k2), the frame's
-//              16x16 block is transposed through the wave's LDS slice (real parts, then imaginary parts,
-//              XOR-swizzled so that the b32 writes and b128 reads are conflict-free), lane k2 does the second
+//              16x16 block is transposed through the wave's LDS slice (XOR-swizzled; mel kinds: real parts, then
+//              imaginary parts, to keep the slice at 4 KB; spectrogram: complex pairs), lane k2 does the second
 //              16-point FFT over n1.  No workgroup barrier (replaces FFTW R2HC, c/kaldi_mfcc.c:304).
 //   untangle   lanes k2 and 16-k2 swap half of their outputs (ds_bpermute) and each computes the power of
 //              bins k and 256-k for 8 values of k (reference: power, c/kaldi_mfcc.c:307-310).
 //   epilogue   spectrogram: log / energy / Nyquist quirk (c/kaldi_spectrogram.c:236-251), staged in LDS so
 //              the quad's 4 x 257 outputs leave as one contiguous coalesced run.
-//              fbank / mfcc / plp: the tile's 16 x 257 power block is staged in LDS and contracted with the
+//              fbank / mfcc / plp: the tile's 32 x 257 power block is staged in LDS and contracted with the
 //              banded mel matrix on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32 fma chains); MFCC
 //              adds a second MFMA contraction with the lifter-scaled DCT matrix; PLP an MFMA with the IDFT
 //              bases followed by one lane per frame running Levinson-Durbin and the cepstral recursion.
