@@ -1,6 +1,7 @@
 // fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, even frame shift;
-// dithered frames have their own instantiations) and, as zero-padded 512-point frames of which the even bins are kept,
-// 256-point frames (129..256 samples).  Everything else runs on generic_kernels.hip.
+// dithered frames have their own instantiations) and 256-point frames (129..256 samples): two frames per complex
+// transform, or -- dithered -- as zero-padded 512-point frames of which the even bins are kept.  Everything else runs on
+// generic_kernels.hip.
 //
 // Unit of work: a QUAD = 4 consecutive frames of one utterance, owned by ONE 64-lane wavefront
 // (16 lanes per frame).  Mel kinds: a 512-thread workgroup takes a tile of 32 consecutive frames, one quad per wave;
@@ -35,13 +36,16 @@ namespace speech {
 
 constexpr int MAX_MTILES = 8;            // mel tiles of up to 16 columns (B <= 128), balanced over the waves; cepstral tiles of 16 (C <= 96)
 
+struct FastGeom { bool ok, pair; int fw, nz, tile; size_t span, ws, lds; };      // launch geometry of a plan, fast_geom()
+
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[8][16] complex
     float *d_melw;     // banded mel matrix: per 16-mel tile, [4 * ksteps][16] weights of FFT bins kbeg .. kbeg + 4 ksteps - 1
     float *d_mat2;     // mfcc: lifter-scaled DCT matrix [Bp4][Cp]; plp: IDFT bases [K4][16]
     float *d_aux;      // plp: eql[B] | lift[C]
-    int nz;            // ceil(L / 32): rows of 32 samples that hold data
-    int bshift, F;     // 256-point plans: bshift 1, F = 129 bins (the even bins of the 512-point transform); else 0, 257
+    int nz;            // rows of samples that hold data: ceil(L / 32), pair mode ceil(L / 16)
+    int bshift, F;     // dithered 256-point plans: bshift 1, F = 129 bins (the even bins of the 512-point transform); else 0
+    FastGeom geom;
     int kind, B, C, P, D, MP, Cp, K2, ntile_m, ntile_c;
     int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES], mel_first[MAX_MTILES], mel_cnt[MAX_MTILES];
 };
@@ -54,16 +58,15 @@ constexpr int QF = 4;                   // frames per wave (quad)
 constexpr int MW = 8;                   // waves per workgroup, mel kinds: with 32 frames the matrix-core phases have two row tiles
                                         // per mel tile, i.e. a job for every wave, and half as many workgroup barriers per frame
 constexpr int NTM = 64 * MW;            // threads per workgroup, mel kinds
-constexpr int TILE = QF * MW;           // frames per workgroup, mel kinds
-constexpr int RT = TILE / 16;           // 16-frame row tiles of the MFMA contractions
+
 constexpr int TILE_SPEC = 64;  // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
-constexpr int SUB = 16;                 // frames per sub-tile
 constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
 constexpr int TR_WAVE_C = 2048;         // floats of a wave's slice when the transposition image is complex (spectrogram kernel)
 constexpr int NFFT = 512, NC = 256;
 constexpr int TAB_WIN = 0, TAB_TW1 = 512, TAB_TW2 = 1024, TAB_FLOATS = 1024 + 8 * 16 * 2;
 constexpr int TR_WAVE = 1032;           // floats of a wave's LDS slice: 4 frames x 16 x 16 reals (transposition image of the real, then the
                                         // imaginary parts), 4 x 257 outputs; four slices = the 16 x 258 power tile
+constexpr int PP2 = 130;                // pitch of the 64 x 129 power tile of the pair mode (also = 2 mod 32)
 constexpr int PP = 258;                 // pitch of the TILE x 257 power tile (= 2 mod 32: conflict-free MFMA operand reads)
 constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
@@ -287,11 +290,75 @@ __device__ __forceinline__ void store_run(float *y, const float *s_src, int nout
 // On return lane k2 (= lane & 15) holds, for k1 = 0..7 (and k1 = 8, meaningful in lane k2 == 0 only):
 //   pa[k1] = 4 |X[k]|^2, pb[k1] = 4 |X[256 - k]|^2 with k = k2 + 16 k1 (the factor 4 is folded into what consumes them);
 //   rawe = the frame's (floored) energy.
+// 256-point complex FFT of z[n], n = n1 + 16 n2, lane n1 holding z[n1 + 16 n2] in z[n2]: 16-point FFT over n2 in registers,
+// twiddle W256^(n1 k2), transposition through the wave's LDS slice, 16-point FFT over n1.  On return lane k2 (= n1) holds
+// Z[k2 + 16 k1] at position P16(k1).
+template <bool HALF>
+__device__ __forceinline__ void fft256(f2 (&z)[16], const float *s_tab, float *s_tr, const int lane)
+{
+    const int f = lane >> 4, n1 = lane & 15;
+    fft16(z);
+    const f2 *tw1 = reinterpret_cast<const f2 *>(s_tab + TAB_TW1);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) { z[P16(k2)] = cmul(z[P16(k2)], tw1[k2 * 16 + n1]); }
+    wave_sync();                                                            // every lane has its samples: the slice becomes the transposition image
+    const int k2 = n1;                                                      // the lane's role after the transpose
+    if (HALF)
+    {
+        // real parts then imaginary parts (a 1 KB image per frame keeps 7 workgroups on a CU): element (k2, n) lives at
+        // 16 k2 + 4 ((n>>2) ^ (k2>>2)) + (n&3), which makes the b32 writes and the b128 reads conflict-free
+        float *trf = s_tr + f * 256;
+        int woff[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
+        const float *rrow = trf + k2 * 16;
+        const int rq = k2 >> 2;
+        float4 rr[4];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].x; }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { rr[q] = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2)); }
+        wave_sync();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].y; }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
+            const f2 r01 = {rr[q].x, rr[q].y}, r23 = {rr[q].z, rr[q].w}, i01 = {v.x, v.y}, i23 = {v.z, v.w};
+            z[4 * q] = pair_lo(r01, i01); z[4 * q + 1] = pair_hi(r01, i01); z[4 * q + 2] = pair_lo(r23, i23); z[4 * q + 3] = pair_hi(r23, i23);
+        }
+    }
+    else
+    {
+        // complex image (2 KB per frame): element (k2, n) lives at float offset 32 k2 + 4 ((n>>1) ^ (k2>>1)) + 2 (n&1):
+        // b64 writes and b128 reads are both conflict-free and the pairs come back as pairs
+        float *trf = s_tr + f * 512;
+        const int wlo = 2 * (n1 & 1), wm = n1 >> 1;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { *reinterpret_cast<f2 *>(trf + 32 * kk + 4 * (wm ^ (kk >> 1)) + wlo) = z[P16(kk)]; }
+        wave_sync();
+        const float *rrow = trf + 32 * k2;
+        const int rg = k2 >> 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(rrow + 4 * (m ^ rg));
+            z[2 * m] = f2{v.x, v.y}; z[2 * m + 1] = f2{v.z, v.w};
+        }
+    }
+    wave_sync();
+    fft16(z);                                                               // Z[k2 + 16 k1] at position P16(k1)
+
+}
+
 template <int NZ, bool HALF, bool DITHER>
 __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
                                             const unsigned long long dkey, float (&pa)[9], float (&pb)[9], float &rawe)
 {
-    const int f = lane >> 4, n1 = lane & 15;
+    const int n1 = lane & 15;
     const int L = p.L;
     const int llast = 2 * n1 + 32 * (NZ - 1);
     const bool ve = llast < L, vo = llast + 1 < L;                          // validity of the lane's two samples in row NZ-1
@@ -379,61 +446,8 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
     }
     rawe = fmaxf(row16_sum(e2.x + e2.y), FLT_EPSILON);
 
-    // first 16-point FFT over n2, twiddle W256^(n1 k2), transpose through the wave's LDS slice
-    fft16(z);
-    const f2 *tw1 = reinterpret_cast<const f2 *>(s_tab + TAB_TW1);
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) { z[P16(k2)] = cmul(z[P16(k2)], tw1[k2 * 16 + n1]); }
-    wave_sync();                                                            // every lane has its samples: the slice becomes the transposition image
+    fft256<HALF>(z, s_tab, s_tr, lane);
     const int k2 = n1;                                                      // the lane's role after the transpose
-    if (HALF)
-    {
-        // real parts then imaginary parts (a 1 KB image per frame keeps 7 workgroups on a CU): element (k2, n) lives at
-        // 16 k2 + 4 ((n>>2) ^ (k2>>2)) + (n&3), which makes the b32 writes and the b128 reads conflict-free
-        float *trf = s_tr + f * 256;
-        int woff[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
-        const float *rrow = trf + k2 * 16;
-        const int rq = k2 >> 2;
-        float4 rr[4];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].x; }
-        wave_sync();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { rr[q] = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2)); }
-        wave_sync();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].y; }
-        wave_sync();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-        {
-            const float4 v = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2));
-            const f2 r01 = {rr[q].x, rr[q].y}, r23 = {rr[q].z, rr[q].w}, i01 = {v.x, v.y}, i23 = {v.z, v.w};
-            z[4 * q] = pair_lo(r01, i01); z[4 * q + 1] = pair_hi(r01, i01); z[4 * q + 2] = pair_lo(r23, i23); z[4 * q + 3] = pair_hi(r23, i23);
-        }
-    }
-    else
-    {
-        // complex image (2 KB per frame): element (k2, n) lives at float offset 32 k2 + 4 ((n>>1) ^ (k2>>1)) + 2 (n&1):
-        // b64 writes and b128 reads are both conflict-free and the pairs come back as pairs
-        float *trf = s_tr + f * 512;
-        const int wlo = 2 * (n1 & 1), wm = n1 >> 1;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) { *reinterpret_cast<f2 *>(trf + 32 * kk + 4 * (wm ^ (kk >> 1)) + wlo) = z[P16(kk)]; }
-        wave_sync();
-        const float *rrow = trf + 32 * k2;
-        const int rg = k2 >> 1;
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-        {
-            const float4 v = *reinterpret_cast<const float4 *>(rrow + 4 * (m ^ rg));
-            z[2 * m] = f2{v.x, v.y}; z[2 * m + 1] = f2{v.z, v.w};
-        }
-    }
-    wave_sync();
-    fft16(z);                                                               // Z[k2 + 16 k1] at position P16(k1)
 
     // untangle: partner lane (16 - k2) mod 16 of the same row holds Z[256 - k] in register 15 - k1; lane 0 is its own
     // partner with register (16 - k1) mod 16
@@ -465,6 +479,100 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
     }
 }
 
+// 256-point plans without dither: TWO real frames per complex transform.  z[n] = xA[n] + i xB[n] (n < 256, frames A and B
+// of the same utterance, B one frame shift after A) goes through the same 256-point complex FFT, and
+//   2 XA[k] = Z[k] + conj Z[256-k],   2 XB[k] = -i (Z[k] - conj Z[256-k])
+// are the untangle step without its twiddle: a wave carries 8 frames (4 pairs, 16 lanes per pair) for the arithmetic of 4.
+// NZ = ceil(L / 16) rows of 16 samples hold data.  fa = frame A's first sample in the slice, bofs = floats from there to
+// frame B's (0 when B does not exist: its lanes then repeat A and their results are dropped).
+// pa[k1] / pb[k1] = 4 |XA[k]|^2 / 4 |XB[k]|^2 for k = k2 + 16 k1 (k1 < 8) and, on lane k2 = 0, k1 = 8: bin 128.
+template <int NZ, bool HALF>
+__device__ __forceinline__ void frame_power_pair(const float *fa, const int bofs, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
+                                                 float (&pa)[9], float (&pb)[9], f2 &rawe)
+{
+    const int n1 = lane & 15;
+    const int L = p.L;
+    const bool vl = n1 + 16 * (NZ - 1) < L;                                 // validity of the lane's sample in row NZ-1
+    const float *fb = fa + bofs;
+    f2 z[16];
+    f2 sum2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2)
+    {
+        if (n2 < NZ)
+        {
+            f2 v = {fa[n1 + 16 * n2], fb[n1 + 16 * n2]};
+            if (n2 == NZ - 1) { v.x = vl ? v.x : 0.0f; v.y = vl ? v.y : 0.0f; }
+            z[n2] = v;
+            sum2 += v;
+        }
+        else { z[n2] = f2{0.0f, 0.0f}; }
+    }
+    f2 mean2 = {0.0f, 0.0f};
+    if (p.dc0) { mean2 = f2{row16_sum(sum2.x) / (float)L, row16_sum(sum2.y) / (float)L}; }      // c/kaldi_mfcc.c:265-271, per frame
+    const float npre = -p.preemph;
+    const f2 npre2 = {npre, npre};
+    const f2 *win2 = reinterpret_cast<const f2 *>(s_tab + TAB_WIN);         // (w[n], w[n]) pairs in this mode
+    f2 e2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int n2 = 0; n2 < NZ; ++n2)
+    {
+        z[n2] -= mean2;
+        if (n2 == NZ - 1) { z[n2].x = vl ? z[n2].x : 0.0f; z[n2].y = vl ? z[n2].y : 0.0f; }
+    }
+    if (p.want_pre)                                                         // c/kaldi_mfcc.c:274-279
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
+    }
+    const int nprev0 = (n1 > 0) ? n1 - 1 : 0;                               // sample before n (itself for n = 0)
+#pragma unroll
+    for (int n2 = 0; n2 < NZ; ++n2)
+    {
+        // pre-emphasis y[n] = d[n] - p d[n-1], y[0] = d[0] - p d[0] (c/kaldi_mfcc.c:282-288), both frames at once
+        const int np = (n2 == 0) ? nprev0 : n1 + 16 * n2 - 1;
+        const f2 prev = f2{fa[np], fb[np]} - mean2;
+        f2 y = __builtin_elementwise_fma(npre2, prev, z[n2]);
+        y *= win2[n1 + 16 * n2];                                            // window: c/kaldi_mfcc.c:291 (table is zero beyond L)
+        if (n2 == NZ - 1) { y.x = vl ? y.x : 0.0f; y.y = vl ? y.y : 0.0f; }
+        z[n2] = y;
+    }
+    if (p.want_post)                                                        // c/kaldi_mfcc.c:295-301
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
+    }
+    rawe = f2{fmaxf(row16_sum(e2.x), FLT_EPSILON), fmaxf(row16_sum(e2.y), FLT_EPSILON)};
+
+    fft256<HALF>(z, s_tab, s_tr, lane);
+    const int k2 = n1;
+
+    // partner lane (16 - k2) mod 16 holds Z[256 - k] in register 15 - k1; lane 0 is its own partner with register (16 - k1) mod 16
+    const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
+    const bool lane0 = (k2 == 0);
+    {
+        const f2 q8 = z[P16(8)] * z[P16(8)];                                // bin 128 (lane 0): XA = Re Z[128], XB = Im Z[128]
+        pa[8] = 4.0f * q8.x;
+        pb[8] = 4.0f * q8.y;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+    {
+        const f2 zo = z[P16((15 - k1) & 15)], zs = z[P16((16 - k1) & 15)];
+        f2 zp;
+        zp.x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.x)));
+        zp.y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.y)));
+        zp.x = lane0 ? zs.x : zp.x;
+        zp.y = lane0 ? zs.y : zp.y;
+        const f2 zk = z[P16(k1)];
+        const f2 e = add_conj(zk, zp);                                      // 2 XA[k]
+        const f2 o = mi_sub_conj(zk, zp);                                   // 2 XB[k]
+        const f2 qe = e * e, qo = o * o;
+        pa[k1] = qe.x + qe.y;
+        pb[k1] = qo.x + qo.y;
+    }
+}
+
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one contiguous run of
 // tiles (neighbouring tiles share L - stp of their samples: the overlap then hits in that XCD's L2).
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t ntiles)
@@ -483,9 +591,9 @@ __device__ __forceinline__ int opaque_zero()
 }
 
 // Geometry of the quad whose first frame is tile-relative frame fq: frames, first sample, samples needed.
-__device__ __forceinline__ int quad_geom(const FastParams &p, const TileDesc &tile, int fq, long long &s0, int &need)
+__device__ __forceinline__ int quad_geom(const FastParams &p, const TileDesc &tile, int fq, long long &s0, int &need, const int fw = QF)
 {
-    const int nfr = min((int)tile.nframes - fq, QF);
+    const int nfr = min((int)tile.nframes - fq, fw);
     const long long w0 = (long long)tile.frame0 + fq;
     s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));     // c/kaldi_mfcc.c:81-82
     need = (nfr - 1) * p.stp + p.L;
@@ -536,7 +644,9 @@ __device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, 
     else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
 }
 
-template <int NZ, bool DITHER, bool PCM>
+// PAIR (256-point plans without dither): a wave carries 8 frames as 4 pairs (frame_power_pair), a sub-tile is 32 frames, a
+// tile 128; NZ then counts rows of 16 samples.
+template <int NZ, bool DITHER, bool PCM, bool PAIR>
 __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -552,26 +662,37 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     const float *xu = p.X + ((p.ablate & 16) ? 0 : utt.x_off);
     const short *xu16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
-    const int nsub = ((int)tile.nframes + SUB - 1) / SUB;
+    constexpr int FW = PAIR ? 2 * QF : QF;                                  // frames per wave
+    constexpr int SUBF = (NT / 64) * FW;                                    // frames per sub-tile
+    const int nsub = ((int)tile.nframes + SUBF - 1) / SUBF;
     const unsigned long long dkey_utt = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) : 0ull;
     long long s0; int need;
-    int nfr = quad_geom(p, tile, wv * QF, s0, need);
+    int nfr = quad_geom(p, tile, wv * FW, s0, need, FW);
     if (nfr > 0) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
     __syncthreads();                                                        // tables (and, wave-locally, the first span) are in LDS
 
     const int f = lane >> 4, k2 = lane & 15;
     for (int it = 0; it < nsub; ++it)
     {
-        const int fq = it * SUB + wv * QF;                                  // this wave's quad in sub-tile `it`
+        const int fq = it * SUBF + wv * FW;                                  // this wave's quad in sub-tile `it`
         long long s0n; int needn;
-        const int nfrn = quad_geom(p, tile, fq + SUB, s0n, needn);
+        const int nfrn = quad_geom(p, tile, fq + SUBF, s0n, needn, FW);
         Prefetch pf;
         prefetch_issue<PCM>(pf, p, xu, xu16, s0n, needn, N, nfrn, lane);
         float pa[9], pb[9], rawe = 1.0f;
+        f2 rawe2 = {1.0f, 1.0f};
         if (nfr > 0)
         {
-            const unsigned long long dkey = dkey_utt + (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL;
-            frame_power<NZ, false, DITHER>(s_aud + f * p.stp, s_tab + opaque_zero(), s_tr, lane, p, dkey, pa, pb, rawe);
+            if (PAIR)
+            {
+                // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its outputs are dropped)
+                frame_power_pair<NZ, false>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab + opaque_zero(), s_tr, lane, p, pa, pb, rawe2);
+            }
+            else
+            {
+                const unsigned long long dkey = dkey_utt + (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL;
+                frame_power<NZ, false, DITHER>(s_aud + f * p.stp, s_tab + opaque_zero(), s_tr, lane, p, dkey, pa, pb, rawe);
+            }
         }
         // The slice is free once the transposition image has been read (inside frame_power): park the next quad now,
         // BEFORE this quad's stores are issued.  The loads were issued ahead of the whole FFT, and vmcnt retires in order,
@@ -590,6 +711,24 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             const int sh = p.bshift, D = p.D;
             const bool live = (k2 & sh) == 0;
             float *st = s_aud + p.span + f * D;
+            if (PAIR)
+            {
+                // pa[k1] / pb[k1]: bin k2 + 16 k1 of frames A / B (D = 129 columns each, B's row right behind A's)
+                float *sta = s_aud + p.span + 2 * f * D, *stb = sta + D;
+                {
+                    const f2 l = spec_log2((k2 == 0) ? 4.0f * rawe2.x : pa[0], (k2 == 0) ? 4.0f * rawe2.y : pb[0]);
+                    sta[k2] = l.x; stb[k2] = l.y;
+                }
+#pragma unroll
+                for (int k1 = 1; k1 < 8; ++k1)
+                {
+                    const f2 l = spec_log2(pa[k1], pb[k1]);
+                    sta[k2 + 16 * k1] = l.x; stb[k2 + 16 * k1] = l.y;
+                    if (k1 == 7 && k2 == 15) { sta[128] = l.x; stb[128] = l.y; }              // last bin := the one before (c/kaldi_spectrogram.c:245-247)
+                }
+            }
+            else
+            {
             {
                 const f2 l = spec_log2((k2 == 0) ? 4.0f * rawe : pa[0], pb[0]);
                 if (live) { st[k2 >> sh] = l.x; }
@@ -603,21 +742,22 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
                 if (live) { st[(k2 + 16 * k1) >> sh] = l.x; st[(NC - k2 - 16 * k1) >> sh] = l.y; }
             }
             if (k2 == 0) { st[128 >> sh] = spec_log(pa[8]); }
+            }
             wave_sync();
             const float *so = s_aud + p.span;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(p.Y + ((p.ablate & 8) ? (unsigned long long)((blockIdx.x & 31u) * TILE_SPEC + (fq & (TILE_SPEC - 1))) * D
+                (void *)(p.Y + ((p.ablate & 8) ? (unsigned long long)((blockIdx.x & 31u) * TILE_SPEC + (fq & (TILE_SPEC - 1))) * D      /* diagnostics */
                                                : utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * D)), 0, (p.ablate & 1) ? 0 : nfr * D * 4, BUF_FLAGS);
-            if (nfr == QF)
+            if (nfr == FW)
             {
-                // QF * D floats = D chunks of 16 bytes (257: four full instructions and one lane; 129: two and one lane)
-                for (int c = lane; c < D; c += 64)
+                // FW * D floats = FW D / 4 chunks of 16 bytes (4 x 257: four full instructions and one lane; 8 x 129: 258 chunks)
+                for (int c = lane; c < FW * D / 4; c += 64)
                 {
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(so + 4 * c);
                     __builtin_amdgcn_raw_buffer_store_b128(v, ry, c * 16, 0, 0);
                 }
             }
-            else                                                            // the last quad of an utterance: 1..3 frames
+            else                                                            // the last quad of an utterance: fewer frames
             {
                 const int n = nfr * D;
                 for (int i = lane; i < n; i += 64) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, so[i]), ry, i * 4, 0, 0); }
@@ -677,29 +817,35 @@ __device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const __amdgpu_bu
 
 // fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
 // Levinson-Durbin and the cepstral recursion stay in registers).
-template <int NZ, int KIND, int P, bool DITHER>
+// PAIR (256-point plans without dither): 8 frames per wave as 4 pairs (frame_power_pair), 64 frames per tile, a 64 x 130
+// power tile; NZ then counts rows of 16 samples.
+template <int NZ, int KIND, int P, bool DITHER, bool PAIR>
 __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
 {
+    constexpr int FWK = PAIR ? 2 * QF : QF;                                 // frames per wave
+    constexpr int TILEK = MW * FWK;                                         // frames per workgroup
+    constexpr int RTK = TILEK / 16;                                         // 16-frame row tiles
+    constexpr int PPK = PAIR ? PP2 : PP;                                     // pitch of the power tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
     float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
-    // after the FFTs the slices are dead and hold the TILE x PP power tile
+    // after the FFTs the slices are dead and hold the TILEK x PPK power tile
     float *s_pow = smem + TAB_FLOATS;
     // private region behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile.  The mfcc / plp output
     // tile (and plp's autocorrelations) are written after the power tile is dead and reuse its place.
     float *s_e = smem + TAB_FLOATS + MW * p.ws;
-    float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILE : s_pow;
-    float *s_mel = s_e + TILE;
-    float *s_ac = s_out + ((TILE * p.D + 3) & ~3);
+    float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILEK : s_pow;
+    float *s_mel = s_e + TILEK;
+    float *s_ac = s_out + ((TILEK * p.D + 3) & ~3);
     for (int i = tid; i < TAB_FLOATS; i += NTM) { s_tab[i] = p.tab[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
-    const int fq = wv * QF;
-    const int nfr = min((int)tile.nframes - fq, QF);
+    const int fq = wv * FWK;
+    const int nfr = min((int)tile.nframes - fq, FWK);
     if (nfr > 0)
     {
         const long long w0 = (long long)tile.frame0 + fq;
@@ -710,7 +856,13 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
 
     const int f = lane >> 4, k2 = lane & 15;
     float pa[9], pb[9], rawe = 1.0f;
-    if (nfr > 0)
+    f2 rawe2 = {1.0f, 1.0f};
+    if (nfr > 0 && PAIR)
+    {
+        // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its row is never stored)
+        frame_power_pair<NZ, true>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab, s_tr, lane, p, pa, pb, rawe2);
+    }
+    else if (nfr > 0)
     {
         const unsigned long long dkey = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) +
                                                       (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL : 0ull;
@@ -722,11 +874,33 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
         for (int i = 0; i < 9; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
     }
     __syncthreads();                                                        // every wave is done with its slice
-    if (p.ablate & 4) { if (pa[0] + pb[3] + rawe == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
+    if (p.ablate & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
-    // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILE x 257 tile, column 257 zero
+    // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILEK x 257 tile, column 257 zero
+    if (PAIR)
     {
-        float *pr = s_pow + (fq + f) * PP;
+        // pa[k1] / pb[k1]: bin k2 + 16 k1 of frames A / B, 129 bins each; column 129 is the zero a padded k-loop may touch
+        float *pra = s_pow + (fq + 2 * f) * PPK, *prb = pra + PPK;
+        if (p.amp)
+        {
+#pragma unroll
+            for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+        {
+            pra[k2 + 16 * k1] = pa[k1];
+            prb[k2 + 16 * k1] = pb[k1];
+        }
+        if (k2 == 0)
+        {
+            pra[128] = pa[8]; prb[128] = pb[8]; pra[129] = 0.0f; prb[129] = 0.0f;
+            s_e[fq + 2 * f] = rawe2.x; s_e[fq + 2 * f + 1] = rawe2.y;
+        }
+    }
+    else
+    {
+        float *pr = s_pow + (fq + f) * PPK;
         if (p.amp)
         {
 #pragma unroll
@@ -746,7 +920,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
         if (k2 == 0)
         {
             pr[128 >> sh] = pa[8]; s_e[fq + f] = rawe;
-            for (int c = (NC >> sh) + 1; c < (sh ? 132 : PP); ++c) { pr[c] = 0.0f; }       // columns a padded k-loop may touch (zero weights)
+            for (int c = (NC >> sh) + 1; c < (sh ? 132 : PPK); ++c) { pr[c] = 0.0f; }       // columns a padded k-loop may touch (zero weights)
         }
     }
     __syncthreads();
@@ -754,11 +928,11 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
     const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
     const int fr0 = (lane >> 4) * 4, col = lane & 15;
-    for (int job = wv; job < RT * p.ntile_m; job += MW)
+    for (int job = wv; job < RTK * p.ntile_m; job += MW)
     {
-        const int t = job / RT, rt = job - t * RT;                          // mel tile, 16-frame row tile
+        const int t = job / RTK, rt = job - t * RTK;                          // mel tile, 16-frame row tile
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * p.mel_ksteps[t], BUF_FLAGS);
-        const f32x4 acc = mfma_tile4(s_pow + (16 * rt + col) * PP + p.mel_kbeg[t] + (lane >> 4), rb, lane * 4, p.mel_ksteps[t]);
+        const f32x4 acc = mfma_tile4(s_pow + (16 * rt + col) * PPK + p.mel_kbeg[t] + (lane >> 4), rb, lane * 4, p.mel_ksteps[t]);
         const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
         const bool live = col < p.mel_cnt[t];
 #pragma unroll
@@ -788,16 +962,16 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
             }
         }
     }
-    if (KIND == SPEECH_FBANK && eo && tid < TILE) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
-    if (KIND == SPEECH_MFCC && tid < 4 * TILE) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
+    if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
+    if (KIND == SPEECH_MFCC && tid < 4 * TILEK) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
     __syncthreads();
 
     if (KIND == SPEECH_MFCC)
     {
         // DCT-II x lifter as a second contraction (c/kaldi_mfcc.c:323-333); the last-cepstrum quirk is a duplicated column
-        for (int job = wv; job < RT * p.ntile_c; job += MW)
+        for (int job = wv; job < RTK * p.ntile_c; job += MW)
         {
-            const int t = job / RT, rt = job - t * RT;
+            const int t = job / RTK, rt = job - t * RTK;
             const f32x4 acc = mfma_tile(s_mel + (16 * rt + col) * p.MP + (lane >> 4), p.mat2 + (lane >> 4) * p.Cp + 16 * t + col, 4 * p.Cp, p.K2 >> 2);
             const int c = 16 * t + col;
 #pragma unroll
@@ -812,14 +986,14 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (KIND == SPEECH_PLP)
     {
         // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames
-        if (wv < RT)
+        if (wv < RTK)
         {
             const f32x4 acc = mfma_tile(s_mel + (16 * wv + col) * p.MP + (lane >> 4), p.mat2 + lane, 64, p.K2 >> 2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s_ac[(16 * wv + fr0 + r) * 17 + col] = acc[r]; }
         }
         __syncthreads();
-        if (tid < TILE)
+        if (tid < TILEK)
         {
             // one lane per frame: Levinson-Durbin with Kaldi's 1 - k^2 >= 1e-5 guard, LPC -> cepstrum, lifter
             // (reference intent c/kaldi_plp.c:206,380-403)
@@ -879,22 +1053,38 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
 
 typedef void (*kernel_fn)(const FastParams);
 
-template <int NZ, bool DITHER>
+template <int NZ, bool DITHER, bool PAIR>
 kernel_fn kernel_for_kind(int kind, bool pcm)
 {
     switch (kind)
     {
-        case SPEECH_SPECTROGRAM: return pcm ? fast_spectrogram_kernel<NZ, DITHER, true> : fast_spectrogram_kernel<NZ, DITHER, false>;
-        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER>;
-        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER>;
-        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER>;
+        case SPEECH_SPECTROGRAM: return pcm ? fast_spectrogram_kernel<NZ, DITHER, true, PAIR> : fast_spectrogram_kernel<NZ, DITHER, false, PAIR>;
+        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER, PAIR>;
+        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER, PAIR>;
+        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER, PAIR>;
     }
 }
 
 // dithered frames have their own instantiations: the generator's temporaries would otherwise cost the plain kernels
 // 13-24 VGPRs and a resident workgroup per CU
 template <int NZ>
-kernel_fn kernel_for_nz(int kind, bool dither, bool pcm) { return dither ? kernel_for_kind<NZ, true>(kind, pcm) : kernel_for_kind<NZ, false>(kind, pcm); }
+kernel_fn kernel_for_nz(int kind, bool dither, bool pcm) { return dither ? kernel_for_kind<NZ, true, false>(kind, pcm) : kernel_for_kind<NZ, false, false>(kind, pcm); }
+
+// two frames per transform (256-point plans without dither): NZ = ceil(L / 16) = 9 .. 16
+kernel_fn kernel_for_pair(int nz, int kind, bool pcm)
+{
+    switch (nz)
+    {
+        case 9: return kernel_for_kind<9, false, true>(kind, pcm);
+        case 10: return kernel_for_kind<10, false, true>(kind, pcm);
+        case 11: return kernel_for_kind<11, false, true>(kind, pcm);
+        case 12: return kernel_for_kind<12, false, true>(kind, pcm);
+        case 13: return kernel_for_kind<13, false, true>(kind, pcm);
+        case 14: return kernel_for_kind<14, false, true>(kind, pcm);
+        case 15: return kernel_for_kind<15, false, true>(kind, pcm);
+        default: return kernel_for_kind<16, false, true>(kind, pcm);
+    }
+}
 
 kernel_fn kernel_for(int nz, int kind, bool dither, bool pcm)
 {
@@ -919,31 +1109,51 @@ int mel_pitch(int cols) { return 32 * ((cols + 31) / 32) + 2; }              // 
 
 }  // namespace
 
-bool fast_supported(const speech_opts &o, size_t L, size_t nfft)
+// Launch geometry of a plan on the tuned kernels: 512-point frames (257..512 samples); 256-point frames (129..256) either two
+// per transform (`pair`: 8 frames per wave) or, when dithered, as zero-padded 512-point frames of which the even bins are kept.
+static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
 {
-    // 512-point frames (257..512 samples), and 256-point frames (129..256) as zero-padded 512-point ones
-    if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u)) { return false; }
+    FastGeom g; memset(&g, 0, sizeof(g));
+    if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u)) { return g; }
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
-    if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return false; }
-    const size_t FBp = nfft / 2u + 1u;
-    const size_t span = ((QF - 1) * stp + 32u * ((L + 31u) / 32u) + 63u) & ~(size_t)63;
-    if (o.kind == SPEECH_SPECTROGRAM) { return (TAB_FLOATS + (NT / 64) * std::max(span + QF * FBp, (size_t)TR_WAVE_C)) * sizeof(float) <= 64u * 1024u; }
-    if (o.B < 2u || o.B > 16u * MAX_MTILES) { return false; }                 // 128 mel bins
+    if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return g; }
+    g.pair = (nfft == (size_t)NFFT / 2u) && !((float)o.dither > FLT_EPSILON);
+    g.fw = g.pair ? 2 * QF : QF;
+    g.nz = g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u);
+    const size_t F = nfft / 2u + 1u, rows = g.pair ? 16u * (size_t)g.nz : 32u * (size_t)g.nz;
+    g.span = (((size_t)g.fw - 1u) * stp + rows + 63u) & ~(size_t)63;        // whole 64-lane load instructions fit the slice
+    if (o.kind == SPEECH_SPECTROGRAM)
+    {
+        g.ws = std::max(g.span + (size_t)g.fw * F, (size_t)TR_WAVE_C);      // + the wave's output, staged behind the parked audio
+        g.tile = (NT / 64) * g.fw * 4;                                      // four sub-tiles
+        g.lds = (TAB_FLOATS + (NT / 64) * g.ws) * sizeof(float);
+        g.ok = g.lds <= 64u * 1024u;
+        return g;
+    }
+    if (o.B < 2u || o.B > 16u * MAX_MTILES) { return g; }                   // 128 mel bins
     size_t D = o.B + (o.use_energy ? 1u : 0u), cols = 0;
-    if (o.kind == SPEECH_MFCC) { if (o.C > 96u) { return false; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
+    if (o.kind == SPEECH_MFCC) { if (o.C > 96u) { return g; } D = o.C; cols = (o.B + 3u) & ~(size_t)3; }
     if (o.kind == SPEECH_PLP)
     {
         const size_t P = (o.lpc_order > 0u) ? o.lpc_order : o.C - 1u;
-        if (P != 12u) { return false; }                                     // the in-register Levinson-Durbin is built for order 12
+        if (P != 12u) { return g; }                                         // the in-register Levinson-Durbin is built for order 12
         D = o.C; cols = (o.B + 2u + 3u) & ~(size_t)3;
     }
-    // the power tile (and the mfcc / plp output and autocorrelation tiles) reuse the wave slices
-    const size_t extra = (size_t)TILE + (o.kind == SPEECH_FBANK ? (((size_t)TILE * D + 3u) & ~(size_t)3) : (size_t)TILE * (size_t)mel_pitch((int)cols));
-    if (((size_t)TILE * D + 3u + (size_t)TILE * 17u) > (size_t)MW * TR_WAVE) { return false; }
-    return (TAB_FLOATS + MW * std::max(span, (size_t)TR_WAVE) + extra) * sizeof(float) <= 64u * 1024u;
+    g.tile = MW * g.fw;
+    const size_t T = (size_t)g.tile;
+    g.ws = std::max(g.span, g.pair ? (T * PP2 + MW - 1) / MW : (size_t)TR_WAVE);     // the slices together hold the power tile
+    // behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile; the mfcc / plp output and
+    // autocorrelation tiles reuse the power tile's place
+    const size_t extra = T + (o.kind == SPEECH_FBANK ? ((T * D + 3u) & ~(size_t)3) : T * (size_t)mel_pitch((int)cols));
+    if (((T * D + 3u) & ~(size_t)3) + T * 17u > (size_t)MW * g.ws) { return g; }
+    g.lds = (TAB_FLOATS + MW * g.ws + extra) * sizeof(float);
+    g.ok = g.lds <= 64u * 1024u;
+    return g;
 }
 
-int fast_tile_frames(const speech_opts &o) { return o.kind == SPEECH_SPECTROGRAM ? TILE_SPEC : TILE; }
+bool fast_supported(const speech_opts &o, size_t L, size_t nfft) { return fast_geom(o, L, nfft).ok; }
+
+int fast_tile_frames(const speech_opts &o, size_t L, size_t nfft) { return fast_geom(o, L, nfft).tile; }
 
 static hipError_t upload_floats(const std::vector<float> &h, float **d)
 {
@@ -962,7 +1172,10 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
 {
     if (err) { err->clear(); }
     std::vector<float> tab(TAB_FLOATS, 0.0f);
-    for (size_t l = 0; l < L && l < (size_t)NFFT; ++l) { tab[TAB_WIN + l] = win[l]; }
+    const FastGeom g = fast_geom(o, L, nfft);
+    if (!g.ok) { return nullptr; }
+    if (g.pair) { for (size_t l = 0; l < L; ++l) { tab[TAB_WIN + 2 * l] = win[l]; tab[TAB_WIN + 2 * l + 1] = win[l]; } }      // (w, w): one factor for frame A and B
+    else { for (size_t l = 0; l < L && l < (size_t)NFFT; ++l) { tab[TAB_WIN + l] = win[l]; } }
     const long double pi = 3.141592653589793238462643383279502884L;
     for (int k2 = 0; k2 < 16; ++k2) { for (int n1 = 0; n1 < 16; ++n1) {
         const long double a = -2.0L * pi * (long double)(n1 * k2) / (long double)NC;
@@ -973,11 +1186,11 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     FastTables *t = new (std::nothrow) FastTables();
     if (!t) { if (err) { *err = "out of host memory"; } return nullptr; }
     t->d_tab = t->d_melw = t->d_mat2 = t->d_aux = nullptr;
-    t->nz = (int)((L + 31u) / 32u); t->kind = o.kind;
+    t->nz = g.nz; t->kind = o.kind; t->geom = g;
     t->B = t->C = t->P = t->MP = t->Cp = t->K2 = t->ntile_m = t->ntile_c = 0;
-    t->bshift = (nfft == (size_t)NFFT / 2u) ? 1 : 0; t->F = (int)(nfft / 2u + 1u);
+    t->bshift = (nfft == (size_t)NFFT / 2u && !g.pair) ? 1 : 0; t->F = (int)(nfft / 2u + 1u);
     t->D = t->F;
-    const int klim = t->bshift ? 132 : PP;                                   // power-tile columns a k-loop may touch
+    const int klim = g.pair ? PP2 : (t->bshift ? 132 : PP);                  // power-tile columns a k-loop may touch
     std::vector<float> melw, mat2, aux;
     if (o.kind != SPEECH_SPECTROGRAM)
     {
@@ -1071,9 +1284,9 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     memset(&p, 0, sizeof(p));
     p.X = fp.X; p.X16 = fp.X16; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
-    p.span = ((QF - 1) * fp.stp + 32 * t->nz + 63) & ~63;     // whole 64-lane load instructions fit the slice
+    const FastGeom &g = t->geom;
+    p.span = (int)g.span; p.ws = (int)g.ws;
     p.bshift = t->bshift;
-    p.ws = (t->kind == SPEECH_SPECTROGRAM) ? std::max(p.span + QF * t->F, TR_WAVE_C) : std::max(p.span, TR_WAVE);   // spectrogram: + the quad's output, staged behind the parked audio
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.do_dither = fp.do_dither; p.dither = fp.dither; p.seed = fp.seed;
@@ -1084,9 +1297,8 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.amp = fp.amp; p.lg = fp.lg; p.use_energy = fp.use_energy; p.compress_mode = fp.compress_mode; p.compress = fp.compress;
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; p.mel_first[i] = t->mel_first[i]; p.mel_cnt[i] = t->mel_cnt[i]; }
     const bool mel = t->kind != SPEECH_SPECTROGRAM;
-    size_t lds = (size_t)(TAB_FLOATS + (mel ? MW : NT / 64) * p.ws) * sizeof(float);
-    if (mel) { lds += (size_t)(TILE + (t->kind == SPEECH_FBANK ? ((TILE * t->D + 3) & ~3) : TILE * t->MP)) * sizeof(float); }
-    kernel_fn k = kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
+    const size_t lds = g.lds;
+    kernel_fn k = g.pair ? kernel_for_pair(t->nz, t->kind, p.X16 != nullptr) : kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
     {

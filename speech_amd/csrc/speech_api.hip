@@ -25,7 +25,7 @@ namespace speech {
 // fast-path hooks (fast_kernels.hip)
 struct FastTables;
 bool fast_supported(const speech_opts &o, size_t L, size_t nfft);
-int fast_tile_frames(const speech_opts &o);
+int fast_tile_frames(const speech_opts &o, size_t L, size_t nfft);
 FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t stp, size_t nfft, size_t B, size_t C, size_t P,
                                const std::vector<float> &win, const std::vector<float> &f2b, const std::vector<int> &beg,
                                const std::vector<int> &num, const std::vector<float> &dct, const std::vector<float> &lift,
@@ -519,7 +519,7 @@ int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const s
     if (!b) { return fail(fn, "out of host memory"); }
     b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_scratch = nullptr; b->d_mom = nullptr; b->ev0 = b->ev1 = nullptr;
     b->total_samples = b->total_out = b->total_frames = 0;
-    const int tile = p->tuned ? fast_tile_frames(p->o) : GENERIC_TILE_FRAMES;
+    const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : GENERIC_TILE_FRAMES;
     const char *kfn = kind_name(p->o.kind, p->o.dtype);
     b->utts.resize(nutt);
     size_t xo = 0, yo = 0;

@@ -84,6 +84,19 @@ _add("mfcc", 9000, 815, sr=16100.0, fs=10.0)                     # stp=161 (odd)
 for i, kind in enumerate(("spectrogram", "fbank", "mfcc", "plp")):
     _add(kind, 20333, 820 + i, snip=0, use_energy=i % 2) if kind != "spectrogram" else _add(kind, 20333, 820 + i, snip=0)
 
+# 256-point plans on the tuned kernels: two frames per transform (rows of 16 samples, NZ = ceil(L/16) = 9..16), odd and even
+# frame counts (the last pair of an utterance may lack its second frame), several 64 / 128-frame tiles, reflected edges
+for i, fl in enumerate((17.0, 18.5, 20.0, 22.0, 25.0, 27.0, 30.0, 32.0)):
+    _kind = ("spectrogram", "fbank", "mfcc", "plp")[i % 4]
+    _add(_kind, 4500 + 83 * i, 830 + i, sr=8000.0, fl=fl, snip=i % 2, **({} if _kind == "spectrogram" else dict(hif=4000.0)))
+_add("spectrogram", 12011, 840, sr=8000.0, snip=0)
+_add("mfcc", 12091, 841, sr=8000.0, hif=3700.0, fs=5.0, use_energy=1)        # stp=40
+_add("fbank", 12000, 842, sr=8000.0, hif=4000.0, B=40, fs=12.5, amp=1)       # stp=100
+_add("plp", 10333, 843, sr=8000.0, hif=4000.0, snip=0, raw_energy=0, use_energy=1)
+_add("fbank", 5000, 844, sr=16000.0, fl=12.0, fs=6.0, B=30, dc0=0, preemph=0.0, win="hamming")     # L=192 at 16 kHz
+_add("mfcc", 280, 845, sr=8000.0, hif=4000.0)                                 # a single pair: W = 2
+_add("mfcc", 200, 846, sr=8000.0, hif=4000.0)                                 # a single frame: the pair lacks B
+
 # mean normalisation (intended D-wide form; reference-pinned only where D == B)
 _add("fbank", 2500, 700, mn0=1)
 _add("mfcc", 2500, 701, B=40, C=40, mn0=1)
