@@ -96,6 +96,9 @@ _add("plp", 10333, 843, sr=8000.0, hif=4000.0, snip=0, raw_energy=0, use_energy=
 _add("fbank", 5000, 844, sr=16000.0, fl=12.0, fs=6.0, B=30, dc0=0, preemph=0.0, win="hamming")     # L=192 at 16 kHz
 _add("mfcc", 280, 845, sr=8000.0, hif=4000.0)                                 # a single pair: W = 2
 _add("mfcc", 200, 846, sr=8000.0, hif=4000.0)                                 # a single frame: the pair lacks B
+for N in (40, 41, 100, 199, 281):                                              # shorter than a frame: heavy reflection in both frames of a pair
+    _add("spectrogram", N, 850 + N, sr=8000.0, snip=0)
+    _add("plp", N, 850 + N, sr=8000.0, hif=4000.0, snip=0)
 
 # mean normalisation (intended D-wide form; reference-pinned only where D == B)
 _add("fbank", 2500, 700, mn0=1)
