@@ -383,7 +383,7 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
         for (int n2 = 0; n2 < NZ; ++n2)
         {
             float g0, g1;
-            dither_pair(mix64(dkey + (unsigned long long)(n1 + 16 * n2)), p.dither, g0, g1);
+            dither_pair(dither_bits(dkey, (unsigned)(n1 + 16 * n2)), p.dither, g0, g1);
             z[n2] += f2{g0, g1};
             if (n2 == NZ - 1) { z[n2].x = ve ? z[n2].x : 0.0f; z[n2].y = vo ? z[n2].y : 0.0f; }
             sum2 += z[n2];
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             }
             else
             {
-                const unsigned long long dkey = dkey_utt + (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL;
+                const unsigned long long dkey = DITHER ? dither_frame_key(dkey_utt, (unsigned long long)((long long)tile.frame0 + fq + f)) : 0ull;
                 frame_power<NZ, false, DITHER>(s_aud + f * p.stp, s_tab + opaque_zero(), s_tr, lane, p, dkey, pa, pb, rawe);
             }
         }
@@ -864,8 +864,8 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     }
     else if (nfr > 0)
     {
-        const unsigned long long dkey = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) +
-                                                      (unsigned long long)((long long)tile.frame0 + fq + f) * DITHER_FRAME_MUL : 0ull;
+        const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.utt << 32)),
+                                                                  (unsigned long long)((long long)tile.frame0 + fq + f)) : 0ull;
         frame_power<NZ, true, DITHER>(s_aud + f * p.stp, s_tab, s_tr, lane, p, dkey, pa, pb, rawe);
     }
     else

@@ -27,8 +27,10 @@ struct TileDesc {
 
 // Dither (c/kaldi_mfcc.c:243-262: a Box-Muller pair per two samples of every frame, drawn afresh for each frame).  The reference
 // seeds a serial generator from the wall clock; here the pair of samples (2i, 2i+1) of frame w of utterance u takes its
-// 64 random bits from a counter-based hash, so any kernel shape draws the same noise:
-//   h = mix64(mix64(seed ^ u << 32) + w * 0x100000001B3 + i),  u1 = hi32(h) / 2^32,  u2 = lo32(h) / 2^32
+// random bits from a counter-based hash, so any kernel shape draws the same noise:
+//   fk = mix64(mix64(seed ^ u << 32) + w * 0x100000001B3)            once per frame (64-bit, well mixed)
+//   h  = fmix32(lo32(fk) ^ i * 0x9E3779B9) + hi32(fk)                per pair: 32 bits, 8 instructions
+//   u1 = hi16(h) / 2^16,  u2 = lo16(h) / 2^16                        (65536 levels each: |noise| <= 4.7 sigma, ample for dither)
 #if defined(__HIPCC__)
 __host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
 {
@@ -39,22 +41,31 @@ __host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long 
 }
 constexpr unsigned long long DITHER_FRAME_MUL = 0x100000001B3ull;
 
+// key of frame w of an utterance whose key is ku = mix64(seed ^ u << 32)
+__host__ __device__ __forceinline__ unsigned long long dither_frame_key(unsigned long long ku, unsigned long long w) { return mix64(ku + w * DITHER_FRAME_MUL); }
+
+// the 32 random bits of pair i of a frame (murmur3's 32-bit finaliser on the pair counter)
+__host__ __device__ __forceinline__ unsigned dither_bits(unsigned long long fk, unsigned i)
+{
+    unsigned h = (unsigned)fk ^ (i * 0x9E3779B9u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h + (unsigned)(fk >> 32);
+}
+
 // float: hardware log2 / sqrt / sin / cos (arguments in revolutions) -- it is noise; what matters is that the tuned and the
 // generic kernels compute it with the same instructions.  g0 goes to the even sample, g1 to the odd one.
-__device__ __forceinline__ void dither_pair(unsigned long long h, float scale, float &g0, float &g1)
+__device__ __forceinline__ void dither_pair(unsigned h, float scale, float &g0, float &g1)
 {
-    float u1 = (float)(unsigned)(h >> 32) * 2.3283064365386963e-10f;
-    const float u2 = (float)(unsigned)h * 2.3283064365386963e-10f;
-    u1 = fminf(u1, 0.99999994f);
+    const float u1 = (float)(h >> 16) * 1.52587890625e-05f;                  // < 1: 1 - u1 >= 2^-16
+    const float u2 = (float)(h & 0xFFFFu) * 1.52587890625e-05f;
     const float R = scale * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(1.0f - u1));     // sqrt(-2 ln(1-u1))
     g0 = R * __builtin_amdgcn_cosf(u2);
     g1 = R * __builtin_amdgcn_sinf(u2);
 }
-__device__ __forceinline__ void dither_pair(unsigned long long h, double scale, double &g0, double &g1)
+__device__ __forceinline__ void dither_pair(unsigned h, double scale, double &g0, double &g1)
 {
-    double u1 = (double)(unsigned)(h >> 32) * 2.3283064365386963e-10;
-    const double u2 = (double)(unsigned)h * 2.3283064365386963e-10;
-    if (u1 > 0.99999994) { u1 = 0.99999994; }
+    const double u1 = (double)(h >> 16) * 1.52587890625e-05;
+    const double u2 = (double)(h & 0xFFFFu) * 1.52587890625e-05;
     const double R = scale * ::sqrt(-2.0 * ::log(1.0 - u1));
     const double ang = 6.283185307179586476925286766559 * u2;
     g0 = R * ::cos(ang);

@@ -340,8 +340,12 @@ def test_dithered_frames_tuned_and_generic_draw_the_same_noise(kind, o):
             outs[dither, fg] = Y.cpu().numpy()
     assert np.isfinite(outs[4.0, 0]).all()
     clean = np.abs(outs[0.0, 0] - outs[0.0, 1]).max()
-    assert np.abs(outs[4.0, 0] - outs[4.0, 1]).max() <= max(2e-4, 2.0 * clean), clean
-    assert np.abs(outs[4.0, 0] - outs[0.0, 0]).max() > 1e-3
+    both = np.abs(outs[4.0, 0] - outs[4.0, 1]).max()
+    effect = np.abs(outs[4.0, 0] - outs[0.0, 0]).max()
+    # the two kernels differ by FFT rounding only (a few times the undithered distance: the weakest bins move with the noise
+    # realisation), which is far below what the dither itself does to the features -- different noise would be of that size
+    assert both <= max(2e-4, 4.0 * clean), (both, clean)
+    assert effect > 1e-3 and both < 0.05 * effect, (both, effect)
 
 
 def test_which_plans_run_on_the_tuned_kernels():
