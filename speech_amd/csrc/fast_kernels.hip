@@ -1,7 +1,6 @@
 // fast_kernels.hip -- tuned gfx950 fp32 kernels for 512-point frames (257..512 samples per frame, even frame shift;
-// dithered frames have their own instantiations) and 256-point frames (129..256 samples): two frames per complex
-// transform, or -- dithered -- as zero-padded 512-point frames of which the even bins are kept.  Everything else runs on
-// generic_kernels.hip.
+// dithered frames have their own instantiations) and 256-point frames (129..256 samples), two frames per complex
+// transform.  Everything else runs on generic_kernels.hip.
 //
 // Unit of work: a QUAD = 4 consecutive frames of one utterance, owned by ONE 64-lane wavefront
 // (16 lanes per frame).  Mel kinds: a 512-thread workgroup takes a tile of 32 consecutive frames, one quad per wave;
@@ -44,7 +43,7 @@ struct FastTables {
     float *d_mat2;     // mfcc: lifter-scaled DCT matrix [Bp4][Cp]; plp: IDFT bases [K4][16]
     float *d_aux;      // plp: eql[B] | lift[C]
     int nz;            // rows of samples that hold data: ceil(L / 32), pair mode ceil(L / 16)
-    int bshift, F;     // dithered 256-point plans: bshift 1, F = 129 bins (the even bins of the 512-point transform); else 0
+    int F;             // bins: 257, or 129 for 256-point plans
     FastGeom geom;
     int kind, B, C, P, D, MP, Cp, K2, ntile_m, ntile_c;
     int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES], mel_first[MAX_MTILES], mel_cnt[MAX_MTILES];
@@ -79,8 +78,6 @@ struct FastParams {
     uint32_t ntiles;
     int L, stp, D, span, ws;            // span: floats of a quad's audio, rounded up to 64; ws: floats of a wave's LDS slice (>= span, TR_WAVE)
     int snip_edges, dc0, want_pre, want_post;
-    int bshift;                         // 0: 512-point frames; 1: 256-point frames (129..256 samples) run as zero-padded 512-point
-                                        // frames -- X256[k] = X512[2k] exactly -- and only the even bins are handed on
     float preemph;                      // 0 when pre-emphasis is off
     int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
     float dither;
@@ -479,15 +476,16 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
     }
 }
 
-// 256-point plans without dither: TWO real frames per complex transform.  z[n] = xA[n] + i xB[n] (n < 256, frames A and B
+// 256-point plans: TWO real frames per complex transform.  z[n] = xA[n] + i xB[n] (n < 256, frames A and B
 // of the same utterance, B one frame shift after A) goes through the same 256-point complex FFT, and
 //   2 XA[k] = Z[k] + conj Z[256-k],   2 XB[k] = -i (Z[k] - conj Z[256-k])
 // are the untangle step without its twiddle: a wave carries 8 frames (4 pairs, 16 lanes per pair) for the arithmetic of 4.
 // NZ = ceil(L / 16) rows of 16 samples hold data.  fa = frame A's first sample in the slice, bofs = floats from there to
 // frame B's (0 when B does not exist: its lanes then repeat A and their results are dropped).
 // pa[k1] / pb[k1] = 4 |XA[k]|^2 / 4 |XB[k]|^2 for k = k2 + 16 k1 (k1 < 8) and, on lane k2 = 0, k1 = 8: bin 128.
-template <int NZ, bool HALF>
+template <int NZ, bool HALF, bool DITHER>
 __device__ __forceinline__ void frame_power_pair(const float *fa, const int bofs, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
+                                                 const unsigned long long dkey_a, const unsigned long long dkey_b,
                                                  float (&pa)[9], float (&pb)[9], f2 &rawe)
 {
     const int n1 = lane & 15;
@@ -508,6 +506,18 @@ __device__ __forceinline__ void frame_power_pair(const float *fa, const int bofs
         }
         else { z[n2] = f2{0.0f, 0.0f}; }
     }
+    if (DITHER)                                                             // c/kaldi_mfcc.c:243-262: sample n is member n & 1 of Box-Muller pair n >> 1
+    {
+        sum2 = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            const unsigned i = (unsigned)(n1 + 16 * n2) >> 1;
+            z[n2] += f2{dither_one(dither_bits(dkey_a, i), p.dither, n1 & 1), dither_one(dither_bits(dkey_b, i), p.dither, n1 & 1)};
+            if (n2 == NZ - 1) { z[n2].x = vl ? z[n2].x : 0.0f; z[n2].y = vl ? z[n2].y : 0.0f; }
+            sum2 += z[n2];
+        }
+    }
     f2 mean2 = {0.0f, 0.0f};
     if (p.dc0) { mean2 = f2{row16_sum(sum2.x) / (float)L, row16_sum(sum2.y) / (float)L}; }      // c/kaldi_mfcc.c:265-271, per frame
     const float npre = -p.preemph;
@@ -526,6 +536,24 @@ __device__ __forceinline__ void frame_power_pair(const float *fa, const int bofs
         for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
     }
     const int nprev0 = (n1 > 0) ? n1 - 1 : 0;                               // sample before n (itself for n = 0)
+    if (DITHER)
+    {
+        // the dithered samples exist in registers only: the sample before n is the lane to the left in the same row (DPP
+        // rotate within the pair's 16 lanes), for lane 0 that of lane 15 one row up
+        f2 up = z[0];                                                       // n = 0: y[0] = d[0] - p d[0]
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            const f2 left = {dpp_mov<0x121>(z[n2].x), dpp_mov<0x121>(z[n2].y)};     // row_ror:1
+            const f2 prev = {(n1 == 0) ? up.x : left.x, (n1 == 0) ? up.y : left.y};
+            up = left;
+            f2 y = __builtin_elementwise_fma(npre2, prev, z[n2]);
+            y *= win2[n1 + 16 * n2];
+            if (n2 == NZ - 1) { y.x = vl ? y.x : 0.0f; y.y = vl ? y.y : 0.0f; }
+            z[n2] = y;
+        }
+    }
+    else
 #pragma unroll
     for (int n2 = 0; n2 < NZ; ++n2)
     {
@@ -644,7 +672,7 @@ __device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, 
     else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
 }
 
-// PAIR (256-point plans without dither): a wave carries 8 frames as 4 pairs (frame_power_pair), a sub-tile is 32 frames, a
+// PAIR (256-point plans): a wave carries 8 frames as 4 pairs (frame_power_pair), a sub-tile is 32 frames, a
 // tile 128; NZ then counts rows of 16 samples.
 template <int NZ, bool DITHER, bool PCM, bool PAIR>
 __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
@@ -686,7 +714,9 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             if (PAIR)
             {
                 // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its outputs are dropped)
-                frame_power_pair<NZ, false>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab + opaque_zero(), s_tr, lane, p, pa, pb, rawe2);
+                const unsigned long long wa = (unsigned long long)((long long)tile.frame0 + fq + 2 * f);
+                const unsigned long long ka = DITHER ? dither_frame_key(dkey_utt, wa) : 0ull, kb = DITHER ? dither_frame_key(dkey_utt, wa + 1) : 0ull;
+                frame_power_pair<NZ, false, DITHER>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab + opaque_zero(), s_tr, lane, p, ka, kb, pa, pb, rawe2);
             }
             else
             {
@@ -707,9 +737,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             // The quad's 4 x 257 outputs are contiguous in Y: they are put in order in the slice behind the parked audio and
             // leave as 16-byte stores, 1 KB of whole cache lines per instruction -- the write path to HBM is bound by
             // requests in flight, and dword stores of 64-byte runs need eight times as many for the same bytes.
-            // 256-point plans keep the even bins only (bshift = 1): bin k of the 512-point transform goes to column k >> 1.
-            const int sh = p.bshift, D = p.D;
-            const bool live = (k2 & sh) == 0;
+            const int D = p.D;
             float *st = s_aud + p.span + f * D;
             if (PAIR)
             {
@@ -731,17 +759,17 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             {
             {
                 const f2 l = spec_log2((k2 == 0) ? 4.0f * rawe : pa[0], pb[0]);
-                if (live) { st[k2 >> sh] = l.x; }
-                if (live && k2 > 0) { st[(NC - k2) >> sh] = l.y; }
-                if (k2 == (1 << sh)) { st[NC >> sh] = l.y; }                                    // last bin := the one before (c/kaldi_spectrogram.c:245-247)
+                st[k2] = l.x;
+                if (k2 > 0) { st[NC - k2] = l.y; }
+                if (k2 == 1) { st[NC] = l.y; }                                                  // last bin := the one before (c/kaldi_spectrogram.c:245-247)
             }
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1)
             {
                 const f2 l = spec_log2(pa[k1], pb[k1]);
-                if (live) { st[(k2 + 16 * k1) >> sh] = l.x; st[(NC - k2 - 16 * k1) >> sh] = l.y; }
+                st[k2 + 16 * k1] = l.x; st[NC - k2 - 16 * k1] = l.y;
             }
-            if (k2 == 0) { st[128 >> sh] = spec_log(pa[8]); }
+            if (k2 == 0) { st[128] = spec_log(pa[8]); }
             }
             wave_sync();
             const float *so = s_aud + p.span;
@@ -817,7 +845,7 @@ __device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const __amdgpu_bu
 
 // fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
 // Levinson-Durbin and the cepstral recursion stay in registers).
-// PAIR (256-point plans without dither): 8 frames per wave as 4 pairs (frame_power_pair), 64 frames per tile, a 64 x 130
+// PAIR (256-point plans): 8 frames per wave as 4 pairs (frame_power_pair), 64 frames per tile, a 64 x 130
 // power tile; NZ then counts rows of 16 samples.
 template <int NZ, int KIND, int P, bool DITHER, bool PAIR>
 __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
@@ -860,7 +888,10 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (nfr > 0 && PAIR)
     {
         // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its row is never stored)
-        frame_power_pair<NZ, true>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab, s_tr, lane, p, pa, pb, rawe2);
+        const unsigned long long ku = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) : 0ull;
+        const unsigned long long wa = (unsigned long long)((long long)tile.frame0 + fq + 2 * f);
+        const unsigned long long ka = DITHER ? dither_frame_key(ku, wa) : 0ull, kb = DITHER ? dither_frame_key(ku, wa + 1) : 0ull;
+        frame_power_pair<NZ, true, DITHER>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab, s_tr, lane, p, ka, kb, pa, pb, rawe2);
     }
     else if (nfr > 0)
     {
@@ -906,22 +937,13 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
 #pragma unroll
             for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
         }
-        // 256-point plans (bshift = 1): only the even bins exist, bin k of the 512-point transform is column k >> 1
-        const int sh = p.bshift;
-        if ((k2 & sh) == 0)
-        {
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1)
-            {
-                pr[(k2 + 16 * k1) >> sh] = pa[k1];
-                pr[(NC - k2 - 16 * k1) >> sh] = pb[k1];
-            }
-        }
-        if (k2 == 0)
+        for (int k1 = 0; k1 < 8; ++k1)
         {
-            pr[128 >> sh] = pa[8]; s_e[fq + f] = rawe;
-            for (int c = (NC >> sh) + 1; c < (sh ? 132 : PPK); ++c) { pr[c] = 0.0f; }       // columns a padded k-loop may touch (zero weights)
+            pr[k2 + 16 * k1] = pa[k1];
+            pr[NC - k2 - 16 * k1] = pb[k1];
         }
+        if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }       // column 257: the zero a padded k-loop may touch
     }
     __syncthreads();
 
@@ -1070,19 +1092,22 @@ kernel_fn kernel_for_kind(int kind, bool pcm)
 template <int NZ>
 kernel_fn kernel_for_nz(int kind, bool dither, bool pcm) { return dither ? kernel_for_kind<NZ, true, false>(kind, pcm) : kernel_for_kind<NZ, false, false>(kind, pcm); }
 
-// two frames per transform (256-point plans without dither): NZ = ceil(L / 16) = 9 .. 16
-kernel_fn kernel_for_pair(int nz, int kind, bool pcm)
+// two frames per transform (256-point plans): NZ = ceil(L / 16) = 9 .. 16
+template <int NZ>
+kernel_fn kernel_for_pair_nz(int kind, bool dither, bool pcm) { return dither ? kernel_for_kind<NZ, true, true>(kind, pcm) : kernel_for_kind<NZ, false, true>(kind, pcm); }
+
+kernel_fn kernel_for_pair(int nz, int kind, bool dither, bool pcm)
 {
     switch (nz)
     {
-        case 9: return kernel_for_kind<9, false, true>(kind, pcm);
-        case 10: return kernel_for_kind<10, false, true>(kind, pcm);
-        case 11: return kernel_for_kind<11, false, true>(kind, pcm);
-        case 12: return kernel_for_kind<12, false, true>(kind, pcm);
-        case 13: return kernel_for_kind<13, false, true>(kind, pcm);
-        case 14: return kernel_for_kind<14, false, true>(kind, pcm);
-        case 15: return kernel_for_kind<15, false, true>(kind, pcm);
-        default: return kernel_for_kind<16, false, true>(kind, pcm);
+        case 9: return kernel_for_pair_nz<9>(kind, dither, pcm);
+        case 10: return kernel_for_pair_nz<10>(kind, dither, pcm);
+        case 11: return kernel_for_pair_nz<11>(kind, dither, pcm);
+        case 12: return kernel_for_pair_nz<12>(kind, dither, pcm);
+        case 13: return kernel_for_pair_nz<13>(kind, dither, pcm);
+        case 14: return kernel_for_pair_nz<14>(kind, dither, pcm);
+        case 15: return kernel_for_pair_nz<15>(kind, dither, pcm);
+        default: return kernel_for_pair_nz<16>(kind, dither, pcm);
     }
 }
 
@@ -1090,10 +1115,6 @@ kernel_fn kernel_for(int nz, int kind, bool dither, bool pcm)
 {
     switch (nz)
     {
-        case 5: return kernel_for_nz<5>(kind, dither, pcm);
-        case 6: return kernel_for_nz<6>(kind, dither, pcm);
-        case 7: return kernel_for_nz<7>(kind, dither, pcm);
-        case 8: return kernel_for_nz<8>(kind, dither, pcm);
         case 9: return kernel_for_nz<9>(kind, dither, pcm);
         case 10: return kernel_for_nz<10>(kind, dither, pcm);
         case 11: return kernel_for_nz<11>(kind, dither, pcm);
@@ -1109,15 +1130,15 @@ int mel_pitch(int cols) { return 32 * ((cols + 31) / 32) + 2; }              // 
 
 }  // namespace
 
-// Launch geometry of a plan on the tuned kernels: 512-point frames (257..512 samples); 256-point frames (129..256) either two
-// per transform (`pair`: 8 frames per wave) or, when dithered, as zero-padded 512-point frames of which the even bins are kept.
+// Launch geometry of a plan on the tuned kernels: 512-point frames (257..512 samples), or 256-point frames (129..256) two
+// per transform (`pair`: 8 frames per wave).
 static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
 {
     FastGeom g; memset(&g, 0, sizeof(g));
     if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u)) { return g; }
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return g; }
-    g.pair = (nfft == (size_t)NFFT / 2u) && !((float)o.dither > FLT_EPSILON);
+    g.pair = (nfft == (size_t)NFFT / 2u);
     g.fw = g.pair ? 2 * QF : QF;
     g.nz = g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u);
     const size_t F = nfft / 2u + 1u, rows = g.pair ? 16u * (size_t)g.nz : 32u * (size_t)g.nz;
@@ -1188,9 +1209,9 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     t->d_tab = t->d_melw = t->d_mat2 = t->d_aux = nullptr;
     t->nz = g.nz; t->kind = o.kind; t->geom = g;
     t->B = t->C = t->P = t->MP = t->Cp = t->K2 = t->ntile_m = t->ntile_c = 0;
-    t->bshift = (nfft == (size_t)NFFT / 2u && !g.pair) ? 1 : 0; t->F = (int)(nfft / 2u + 1u);
+    t->F = (int)(nfft / 2u + 1u);
     t->D = t->F;
-    const int klim = g.pair ? PP2 : (t->bshift ? 132 : PP);                  // power-tile columns a k-loop may touch
+    const int klim = g.pair ? PP2 : PP;                                      // power-tile columns a k-loop may touch
     std::vector<float> melw, mat2, aux;
     if (o.kind != SPEECH_SPECTROGRAM)
     {
@@ -1286,7 +1307,6 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     const FastGeom &g = t->geom;
     p.span = (int)g.span; p.ws = (int)g.ws;
-    p.bshift = t->bshift;
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.do_dither = fp.do_dither; p.dither = fp.dither; p.seed = fp.seed;
@@ -1298,7 +1318,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; p.mel_first[i] = t->mel_first[i]; p.mel_cnt[i] = t->mel_cnt[i]; }
     const bool mel = t->kind != SPEECH_SPECTROGRAM;
     const size_t lds = g.lds;
-    kernel_fn k = g.pair ? kernel_for_pair(t->nz, t->kind, p.X16 != nullptr) : kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
+    kernel_fn k = g.pair ? kernel_for_pair(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr) : kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
     {

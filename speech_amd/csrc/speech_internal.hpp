@@ -59,8 +59,16 @@ __device__ __forceinline__ void dither_pair(unsigned h, float scale, float &g0, 
     const float u1 = (float)(h >> 16) * 1.52587890625e-05f;                  // < 1: 1 - u1 >= 2^-16
     const float u2 = (float)(h & 0xFFFFu) * 1.52587890625e-05f;
     const float R = scale * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(1.0f - u1));     // sqrt(-2 ln(1-u1))
-    g0 = R * __builtin_amdgcn_cosf(u2);
-    g1 = R * __builtin_amdgcn_sinf(u2);
+    g0 = R * __builtin_amdgcn_sinf(u2 + 0.25f);                              // cos, as the sine a quarter turn on (exact sum): one
+    g1 = R * __builtin_amdgcn_sinf(u2);                                      // code path for dither_one below
+}
+// one member of the pair: odd = 0 the even sample's (g0), 1 the odd sample's (g1); the same bits as dither_pair gives
+__device__ __forceinline__ float dither_one(unsigned h, float scale, int odd)
+{
+    const float u1 = (float)(h >> 16) * 1.52587890625e-05f;
+    const float u2 = (float)(h & 0xFFFFu) * 1.52587890625e-05f;
+    const float R = scale * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(1.0f - u1));
+    return R * __builtin_amdgcn_sinf(u2 + (odd ? 0.0f : 0.25f));
 }
 __device__ __forceinline__ void dither_pair(unsigned h, double scale, double &g0, double &g1)
 {

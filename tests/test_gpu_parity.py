@@ -319,14 +319,16 @@ def test_dither_is_seeded_and_has_the_right_scale():
 
 
 @pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80, snip=0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("plp", {}),
-                                    ("mfcc", dict(fl=17.0, preemph=0.0, dc0=0, raw_energy=0, use_energy=1))])
+                                    ("mfcc", dict(fl=17.0, preemph=0.0, dc0=0, raw_energy=0, use_energy=1)),
+                                    ("mfcc", dict(sr=8000.0, hif=4000.0)), ("spectrogram", dict(sr=8000.0, snip=0)),
+                                    ("fbank", dict(sr=8000.0, hif=3800.0, B=40, fl=32.0, preemph=0.0))])
 def test_dithered_frames_tuned_and_generic_draw_the_same_noise(kind, o):
     """dither (c/kaldi_mfcc.c:243-262) is per frame and counter-based: the tuned kernels (noise added in registers, the
     pre-emphasis neighbour fetched across lanes) and the generic kernel (noise added in LDS) see the same dithered frames,
     so they agree to the bound of the undithered pair; and the noise is really there"""
     import torch
     lens = [24000, 4801]
-    xs = [signals.utterance(n, 90 + i) for i, n in enumerate(lens)]
+    xs = [signals.utterance(n, 90 + i, sr=o.get("sr", 16000.0)) for i, n in enumerate(lens)]
     X = torch.from_numpy(np.concatenate(xs)).cuda()
     outs = {}
     for dither in (0.0, 4.0):
