@@ -30,6 +30,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace speech {
 
@@ -1322,8 +1325,18 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
     {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // opt the kernel in to 64 KB of dynamic LDS (fast_geom admits nothing larger) once per device, not per launch
+        static std::mutex mu;
+        static std::set<std::pair<int, const void *>> opted;
+        int dev = 0;
+        e = hipGetDevice(&dev);
         if (e != hipSuccess) { return e; }
+        std::lock_guard<std::mutex> lock(mu);
+        if (opted.insert(std::make_pair(dev, reinterpret_cast<const void *>(k))).second)
+        {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) { opted.erase(std::make_pair(dev, reinterpret_cast<const void *>(k))); return e; }
+        }
     }
     if (ev0) { e = hipEventRecord(ev0, s); if (e != hipSuccess) { return e; } }
     hipLaunchKernelGGL(k, dim3(fp.ntiles), dim3(mel ? NTM : NT), lds, s, p);
