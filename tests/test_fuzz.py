@@ -1,11 +1,14 @@
 """Differential fuzz of the two HIP implementations: random option sets inside the tuned kernels' envelope (8 / 16 kHz,
 frame lengths 129..512 samples, even shifts, every switch, ragged utterance lengths, both edge modes) must give the same
-features on the tuned and on the generic kernels (force_generic), and the same as the per-utterance drop-in call."""
+features on the tuned and on the generic kernels (force_generic), and pass the parity suite's acceptance rule against the
+CPU oracle."""
 import numpy as np
 import pytest
 
+import np_truth as T
+import oracle_lib as O
 import signals
-from compare import max_err
+from compare import check_parity, max_err
 
 WINDOWS = ("povey", "hamming", "hann", "rectangular", "blackman")
 
@@ -69,6 +72,15 @@ def test_random_option_sets_tuned_equals_generic(seed):
         # cepstra, relative to the frame's largest bin for linear mel energies; two float32 implementations each within
         # the tolerance of the exact result can be twice as far from each other, weak mel bins a little more
         tol = 5e-5 if kind == "spectrogram" else (2e-5 if (kind == "fbank" and not o["lg"]) else 5e-4)
+        # and the acceptance rule of the parity suite against the CPU oracle (exact-FFT and float-FFT) and the float64
+        # statement, on the longest of the utterances
+        u0 = int(np.argmax(lens))
+        x0, got0 = xs[u0], outs[0][u0]
+        _, ref = O.run(kind, x0, single=True, **o)
+        _, ref_fast = O.run(kind, x0, single=True, exact=False, **o)
+        truth = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}[kind](np.asarray(x0, dtype=np.float64), single=True, **o)
+        ok, e_go, e_gt, e_ot = check_parity(kind, o, got0, ref, truth, tol=1e-5 if kind == "spectrogram" else 1e-4, oracle_fast=ref_fast)
+        assert ok, (kind, o, lens[u0], "hip-vs-oracle %.3g, hip-vs-f64 %.3g, f32-cpu-vs-f64 %.3g" % (e_go, e_gt, e_ot))
         for u, (t, g) in enumerate(zip(*outs)):
             if t.shape[0] == 0:
                 continue
