@@ -1179,6 +1179,30 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft) { return fast_g
 
 int fast_tile_frames(const speech_opts &o, size_t L, size_t nfft) { return fast_geom(o, L, nfft).tile; }
 
+// Opt a kernel in to 64 KB of dynamic LDS (fast_geom admits nothing larger), once per device.  Done when the plan is
+// created, so that speech_batch_run itself only launches (and can be captured in a HIP graph).
+static hipError_t opt_in_lds(kernel_fn k)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> opted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { return e; }
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, reinterpret_cast<const void *>(k));
+    if (opted.insert(key).second)
+    {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) { opted.erase(key); }
+    }
+    return e;
+}
+
+static kernel_fn plan_kernel(const FastTables *t, bool dither, bool pcm)
+{
+    return t->geom.pair ? kernel_for_pair(t->nz, t->kind, dither, pcm) : kernel_for(t->nz, t->kind, dither, pcm);
+}
+
 static hipError_t upload_floats(const std::vector<float> &h, float **d)
 {
     *d = nullptr;
@@ -1285,6 +1309,12 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     if (e == hipSuccess) { e = upload_floats(melw, &t->d_melw); }
     if (e == hipSuccess) { e = upload_floats(mat2, &t->d_mat2); }
     if (e == hipSuccess) { e = upload_floats(aux, &t->d_aux); }
+    if (e == hipSuccess && g.lds > 48u * 1024u)
+    {
+        const bool dither = (float)o.dither > FLT_EPSILON;
+        e = opt_in_lds(plan_kernel(t, dither, false));
+        if (e == hipSuccess) { e = opt_in_lds(plan_kernel(t, dither, true)); }
+    }
     if (e != hipSuccess) { if (err) { *err = hipGetErrorString(e); } fast_tables_destroy(t); return nullptr; }
     return t;
 }
@@ -1321,23 +1351,8 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float 
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; p.mel_first[i] = t->mel_first[i]; p.mel_cnt[i] = t->mel_cnt[i]; }
     const bool mel = t->kind != SPEECH_SPECTROGRAM;
     const size_t lds = g.lds;
-    kernel_fn k = g.pair ? kernel_for_pair(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr) : kernel_for(t->nz, t->kind, p.do_dither != 0, p.X16 != nullptr);
+    kernel_fn k = plan_kernel(t, p.do_dither != 0, p.X16 != nullptr);
     hipError_t e = hipSuccess;
-    if (lds > 48 * 1024)
-    {
-        // opt the kernel in to 64 KB of dynamic LDS (fast_geom admits nothing larger) once per device, not per launch
-        static std::mutex mu;
-        static std::set<std::pair<int, const void *>> opted;
-        int dev = 0;
-        e = hipGetDevice(&dev);
-        if (e != hipSuccess) { return e; }
-        std::lock_guard<std::mutex> lock(mu);
-        if (opted.insert(std::make_pair(dev, reinterpret_cast<const void *>(k))).second)
-        {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            if (e != hipSuccess) { opted.erase(std::make_pair(dev, reinterpret_cast<const void *>(k))); return e; }
-        }
-    }
     if (ev0) { e = hipEventRecord(ev0, s); if (e != hipSuccess) { return e; } }
     hipLaunchKernelGGL(k, dim3(fp.ntiles), dim3(mel ? NTM : NT), lds, s, p);
     e = hipGetLastError();

@@ -302,6 +302,33 @@ def test_dropin_calls_from_many_threads():
         assert np.array_equal(g, w), j
 
 
+@pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(sr=8000.0, hif=4000.0))])
+def test_batch_run_can_be_captured_in_a_graph(kind, o):
+    """speech_batch_run only launches (tables, geometry and the large-LDS opt-in belong to plan / batch creation), so a
+    caller can capture it in a HIP graph and replay it: the replay reproduces the eager result bit for bit"""
+    import torch
+    lens = [16000, 4801, 30000]
+    xs = [signals.utterance(n, 40 + i, sr=o.get("sr", 16000.0)) for i, n in enumerate(lens)]
+    plan = api.Plan(kind, **o)
+    b = api.Batch(plan, lens)
+    X = torch.from_numpy(np.concatenate(xs)).cuda()
+    Y = torch.zeros(b.total_out, device="cuda")
+    b.run(X, Y)
+    torch.cuda.synchronize()
+    want = Y.clone()
+    Yg = torch.zeros_like(Y)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            b.run(X, Yg, stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        Yg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert bool((Yg == want).all())
+
+
 def test_dither_is_seeded_and_has_the_right_scale():
     import torch
     x = np.zeros(16000, dtype=np.float32)
