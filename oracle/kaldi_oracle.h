@@ -11,18 +11,23 @@ extern "C" {
 void oracle_set_fft_exact(int exact);   /* 1 (default): FFT/DCT in the wider type, rounded once; 0: working precision */
 int oracle_get_fft_exact(void);
 
-int oracle_kaldi_spectrogram_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const int mn0);
-int oracle_kaldi_spectrogram_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const int mn0);
+/* the arguments every extractor starts with, in the order of the reference's ABI (see include/codee_speech.h) */
+#define ORACLE_FRONT(T) \
+    T *Y, T *X, size_t N, T sr, T frame_length, T frame_shift, int snip_edges, T dither, int dc0, int raw_energy, T preemph, const char win_type[]
+#define ORACLE_MEL(T) T lof, T hif, size_t B
 
-int oracle_kaldi_fbank_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const int amp, const float lof, const float hif, const size_t B, const int lg, const int use_energy, const int mn0);
-int oracle_kaldi_fbank_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const int amp, const double lof, const double hif, const size_t B, const int lg, const int use_energy, const int mn0);
+int oracle_kaldi_spectrogram_s(ORACLE_FRONT(float), int mn0);
+int oracle_kaldi_spectrogram_d(ORACLE_FRONT(double), int mn0);
 
-int oracle_kaldi_mfcc_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const float lof, const float hif, const size_t B, const size_t C, const float Q, const int use_energy, const int mn0);
-int oracle_kaldi_mfcc_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const double lof, const double hif, const size_t B, const size_t C, const double Q, const int use_energy, const int mn0);
+int oracle_kaldi_fbank_s(ORACLE_FRONT(float), int amp, ORACLE_MEL(float), int lg, int use_energy, int mn0);
+int oracle_kaldi_fbank_d(ORACLE_FRONT(double), int amp, ORACLE_MEL(double), int lg, int use_energy, int mn0);
+
+int oracle_kaldi_mfcc_s(ORACLE_FRONT(float), ORACLE_MEL(float), size_t C, float Q, int use_energy, int mn0);
+int oracle_kaldi_mfcc_d(ORACLE_FRONT(double), ORACLE_MEL(double), size_t C, double Q, int use_energy, int mn0);
 
 /* lpc_order == 0 selects the drop-in rule order = C-1 */
-int oracle_kaldi_plp_s(float *Y, float *X, const size_t N, const float sr, const float frame_length, const float frame_shift, const int snip_edges, const float dither, const int dc0, const int raw_energy, const float preemph, const char win_type[], const float lof, const float hif, const size_t B, const float compress, const size_t C, const float Q, const float cep_scale, const int use_energy, const int mn0, const size_t lpc_order);
-int oracle_kaldi_plp_d(double *Y, double *X, const size_t N, const double sr, const double frame_length, const double frame_shift, const int snip_edges, const double dither, const int dc0, const int raw_energy, const double preemph, const char win_type[], const double lof, const double hif, const size_t B, const double compress, const size_t C, const double Q, const double cep_scale, const int use_energy, const int mn0, const size_t lpc_order);
+int oracle_kaldi_plp_s(ORACLE_FRONT(float), ORACLE_MEL(float), float compress, size_t C, float Q, float cep_scale, int use_energy, int mn0, size_t lpc_order);
+int oracle_kaldi_plp_d(ORACLE_FRONT(double), ORACLE_MEL(double), double compress, size_t C, double Q, double cep_scale, int use_energy, int mn0, size_t lpc_order);
 
 int oracle_frame_count_s(size_t N, float sr, float frame_length, float frame_shift, int snip_edges, size_t *W, size_t *L, size_t *stp);
 int oracle_frame_count_d(size_t N, double sr, double frame_length, double frame_shift, int snip_edges, size_t *W, size_t *L, size_t *stp);
