@@ -1,0 +1,76 @@
+// Host-side AddressSanitizer run of libspeech's host layer (validation, table building, mel-tile partition, batch geometry,
+// plan cache, staging) -- device code is untouched.  Built by tools/asan/run.sh with -Xarch_host -fsanitize=address and run
+// on the GPU box; exits non-zero on any ASan report or wrong return code.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../include/codee_speech.h"
+#include "../../include/speech_hip.h"
+
+static int fails = 0;
+#define EXPECT(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++fails; } } while (0)
+
+int main()
+{
+    std::vector<float> x(48000);
+    for (size_t i = 0; i < x.size(); ++i) { x[i] = 1000.0f * sinf(0.01f * (float)i) + (float)((i * 2654435761u) % 2001) - 1000.0f; }
+    std::vector<double> xd(x.begin(), x.end());
+    // drop-in calls over sample rates, mel-bin counts (every tile partition from 2 to 128 bins), cepstra, switches
+    const float srs[] = {8000.0f, 16000.0f, 22050.0f, 44100.0f};
+    for (float sr : srs)
+    {
+        const size_t N = 12000;
+        for (size_t B = 2; B <= 140; B += (B < 24 ? 1 : 7))
+        {
+            const float hif = sr / 2;
+            std::vector<float> y((N / 10 + 8) * (B + 2), 0.0f);
+            EXPECT(codee::kaldi_fbank_s(y.data(), x.data(), N, sr, 25.0f, 10.0f, (int)(B & 1), 0.0f, 1, 1, 0.97f, "povey", 0, 20.0f, hif, B, 1, (int)((B >> 1) & 1), 0) == 0);
+            const size_t C = B < 13 ? B : 13;
+            EXPECT(codee::kaldi_mfcc_s(y.data(), x.data(), N, sr, 25.0f, 10.0f, 1, (B % 5 == 0) ? 1.0f : 0.0f, 1, 1, 0.97f, "hamming", 20.0f, hif, B, C, 22.0f, 0, (int)(B % 3 == 0)) == 0);
+            if (B >= 13) { EXPECT(codee::kaldi_plp_s(y.data(), x.data(), N, sr, 25.0f, 10.0f, 0, 0.0f, 1, 0, 0.97f, "hann", 20.0f, hif, B, 1.0f / 3.0f, 13, 22.0f, 1.0f, 1, 0) == 0); }
+        }
+        std::vector<float> ys((12000 / 10 + 8) * 2049, 0.0f);
+        EXPECT(codee::kaldi_spectrogram_s(ys.data(), x.data(), 12000, sr, 25.0f, 10.0f, 0, 0.0f, 0, 1, 0.0f, "rectangular", 0) == 0);
+        std::vector<double> yd((12000 / 10 + 8) * 2049, 0.0);
+        EXPECT(codee::kaldi_spectrogram_d(yd.data(), xd.data(), 12000, (double)sr, 25.0, 10.0, 1, 0.0, 1, 0, 0.97, "blackman", 1) == 0);
+    }
+    // frame geometry sweep on the tuned path: every zero-padding variant, odd lengths, shifts up to gaps between frames
+    for (float fl = 16.1f; fl <= 32.0f; fl += 0.7f)
+    {
+        for (float fs = 2.0f; fs <= 40.0f; fs += 5.3f)
+        {
+            std::vector<float> y(48000 * 13, 0.0f);
+            EXPECT(codee::kaldi_mfcc_s(y.data(), x.data(), 20000, 16000.0f, fl, fs, 0, 0.0f, 1, 1, 0.97f, "povey", 20.0f, 8000.0f, 23, 13, 22.0f, 0, 0) == 0);
+            EXPECT(codee::kaldi_fbank_s(y.data(), x.data(), 9000, 8000.0f, fl, fs, 1, 0.5f, 1, 1, 0.97f, "povey", 1, 20.0f, 4000.0f, 23, 0, 1, 0) == 0);
+        }
+    }
+    // error paths return 1 and leak nothing
+    std::vector<float> y(4096, 0.0f);
+    EXPECT(codee::kaldi_mfcc_s(y.data(), x.data(), 0, 16000.0f, 25.0f, 10.0f, 1, 0.0f, 1, 1, 0.97f, "povey", 20.0f, 8000.0f, 23, 13, 22.0f, 0, 0) == 1);
+    EXPECT(codee::kaldi_mfcc_s(y.data(), x.data(), 4000, 16000.0f, 25.0f, 10.0f, 1, 0.0f, 1, 1, 0.97f, "nowindow", 20.0f, 8000.0f, 23, 13, 22.0f, 0, 0) == 1);
+    EXPECT(codee::kaldi_mfcc_s(y.data(), x.data(), 4000, 16000.0f, 25.0f, 10.0f, 1, 0.0f, 1, 1, 0.97f, "povey", 20.0f, 8000.0f, 10, 13, 22.0f, 0, 0) == 1);
+    EXPECT(codee::kaldi_fbank_s(y.data(), x.data(), 100, 16000.0f, 25.0f, 10.0f, 1, 0.0f, 1, 1, 0.97f, "povey", 0, 20.0f, 8000.0f, 23, 1, 0, 0) == 1);      // snip_edges && L > N
+    // the batch ABI with ragged lengths, post-processing included
+    speech_opts o; speech_opts_default(&o, SPEECH_MFCC);
+    o.snip_edges = 0; o.dc0 = 1; o.raw_energy = 1;
+    speech_plan *plan = nullptr;
+    EXPECT(speech_plan_create(&plan, &o, 0) == 0);
+    if (plan)
+    {
+        const size_t lens[] = {16000, 1, 399, 400, 401, 47999, 160};
+        speech_batch *b = nullptr;
+        EXPECT(speech_batch_create(&b, plan, 7, lens, nullptr, nullptr) == 0);
+        if (b)
+        {
+            size_t ns = 0, no = 0, nf = 0;
+            EXPECT(speech_batch_totals(b, &ns, &no, &nf) == 0);
+            std::vector<double> sum(13), sq(13); unsigned long long frames = 0;
+            EXPECT(speech_batch_stats(b, nullptr, sum.data(), sq.data(), &frames, nullptr) == 1);      // null device pointer
+            speech_batch_destroy(b);
+        }
+        speech_plan_destroy(plan);
+    }
+    printf("host asan run: %d failure(s)\n", fails);
+    return fails ? 1 : 0;
+}
