@@ -907,7 +907,9 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
 #pragma unroll
         for (int i = 0; i < 9; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
     }
-    __syncthreads();                                                        // every wave is done with its slice
+    // The power tile takes the slices' place.  When a slice is exactly as long as the wave's rows of the tile (the usual
+    // case: ws = FWK * PPK), a wave's rows lie in its own slice and it only has to be done with its own transposition image.
+    if (p.ws != FWK * PPK) { __syncthreads(); } else { wave_sync(); }
     if (p.ablate & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILEK x 257 tile, column 257 zero
