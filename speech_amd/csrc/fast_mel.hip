@@ -1,0 +1,324 @@
+// fast_mel.hip -- the tuned fbank / mfcc / plp kernel: front end + FFT (fast_common.hpp), then the mel filterbank, the
+// DCT or the IDFT as banded f32 MFMA contractions over the tile's power block, and the epilogues.
+#include "fast_common.hpp"
+
+namespace speech {
+namespace {
+
+// One 16 x 16 output tile of  A[16 frames][K] . Bm[K][16]  on the matrix cores.  `arow` points at this lane's A element
+// of k-step 0 (LDS, row pitch chosen so that the 64 b32 reads of a step are conflict-free), `brow` at its Bm element
+// (global, L1/L2-resident; consecutive lanes read consecutive floats), `bstep` = floats between k-steps of Bm.
+// v_mfma_f32_16x16x4_f32 is an exact f32 fma chain in k order; two accumulators hide its 40-cycle dependent latency.
+__device__ __forceinline__ f32x4 mfma_tile(const float *arow, const float *brow, const int bstep, const int ksteps)
+{
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    int s = 0;
+    for (; s + 1 < ksteps; s += 2)
+    {
+        const float a0 = arow[4 * s], b0 = brow[(size_t)s * bstep];
+        const float a1 = arow[4 * s + 4], b1 = brow[(size_t)(s + 1) * bstep];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    }
+    if (s < ksteps) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * s], brow[(size_t)s * bstep], acc0, 0, 0, 0); }
+    return acc0 + acc1;
+}
+
+// The mel contraction: `ksteps` is a multiple of 4 (host pads with zero weights).  Operands of the next four k-steps are
+// loaded while the current four MFMAs run, so the L1/L2 latency of the weights is paid once per tile instead of per step
+// (8 more VGPRs; fetching deeper costs occupancy and measured slower).
+__device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const __amdgpu_buffer_rsrc_t rb, const int bvoff, const int ksteps)
+{
+    // the weights come through a raw buffer descriptor: the lane's byte offset stays in one VGPR and the k-step advances
+    // in an SGPR, so the loop spends no vector instructions on 64-bit addresses
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ksteps <= 0) { return acc0; }
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, bvoff, 256 * j, 0)); a[j] = arow[4 * j]; }
+    for (int s = 0; s < ksteps; s += 4)
+    {
+        const int sn = min(s + 4, ksteps - 4);                              // the last trip reloads its own block (harmless)
+        const float *an_p = arow + 4 * sn;
+        float an[4], bn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bn[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, bvoff, 256 * (sn + j), 0)); an[j] = an_p[4 * j]; }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = an[j]; b[j] = bn[j]; }
+    }
+    return acc0 + acc1;
+}
+
+// fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
+// Levinson-Durbin and the cepstral recursion stay in registers).
+// PAIR (256-point plans): 8 frames per wave as 4 pairs (frame_power_pair), 64 frames per tile, a 64 x 130
+// power tile; NZ then counts rows of 16 samples.
+template <int NZ, int KIND, int P, bool DITHER, bool PAIR>
+__global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
+{
+    constexpr int FWK = PAIR ? 2 * QF : QF;                                 // frames per wave
+    constexpr int TILEK = MW * FWK;                                         // frames per workgroup
+    constexpr int RTK = TILEK / 16;                                         // 16-frame row tiles
+    constexpr int PPK = PAIR ? PP2 : PP;                                     // pitch of the power tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *s_tab = smem;
+    float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image
+    float *s_tr = s_aud;
+    // after the FFTs the slices are dead and hold the TILEK x PPK power tile
+    float *s_pow = smem + TAB_FLOATS;
+    // private region behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile.  The mfcc / plp output
+    // tile (and plp's autocorrelations) are written after the power tile is dead and reuse its place.
+    float *s_e = smem + TAB_FLOATS + MW * p.ws;
+    float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILEK : s_pow;
+    float *s_mel = s_e + TILEK;
+    float *s_ac = s_out + ((TILEK * p.D + 3) & ~3);
+    for (int i = tid; i < TAB_FLOATS; i += NTM) { s_tab[i] = p.tab[i]; }
+
+    const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
+    const UttDesc utt = p.utts[tile.utt];
+    const int fq = wv * FWK;
+    const int nfr = min((int)tile.nframes - fq, FWK);
+    if (nfr > 0)
+    {
+        const long long w0 = (long long)tile.frame0 + fq;
+        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
+        load_span(s_aud, p.X + utt.x_off, p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
+    }
+    __syncthreads();
+
+    const int f = lane >> 4, k2 = lane & 15;
+    float pa[9], pb[9], rawe = 1.0f;
+    f2 rawe2 = {1.0f, 1.0f};
+    if (nfr > 0 && PAIR)
+    {
+        // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its row is never stored)
+        const unsigned long long ku = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) : 0ull;
+        const unsigned long long wa = (unsigned long long)((long long)tile.frame0 + fq + 2 * f);
+        const unsigned long long ka = DITHER ? dither_frame_key(ku, wa) : 0ull, kb = DITHER ? dither_frame_key(ku, wa + 1) : 0ull;
+        frame_power_pair<NZ, true, DITHER>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab, s_tr, lane, p, ka, kb, pa, pb, rawe2);
+    }
+    else if (nfr > 0)
+    {
+        const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.utt << 32)),
+                                                                  (unsigned long long)((long long)tile.frame0 + fq + f)) : 0ull;
+        frame_power<NZ, true, DITHER>(s_aud + f * p.stp, s_tab, s_tr, lane, p, dkey, pa, pb, rawe);
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
+    }
+    // The power tile takes the slices' place.  When a slice is exactly as long as the wave's rows of the tile (the usual
+    // case: ws = FWK * PPK), a wave's rows lie in its own slice and it only has to be done with its own transposition image.
+    if (p.ws != FWK * PPK) { __syncthreads(); } else { wave_sync(); }
+    if (p.ablate & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
+
+    // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILEK x 257 tile, column 257 zero
+    if (PAIR)
+    {
+        // pa[k1] / pb[k1]: bin k2 + 16 k1 of frames A / B, 129 bins each; column 129 is the zero a padded k-loop may touch
+        float *pra = s_pow + (fq + 2 * f) * PPK, *prb = pra + PPK;
+        if (p.amp)
+        {
+#pragma unroll
+            for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+        {
+            pra[k2 + 16 * k1] = pa[k1];
+            prb[k2 + 16 * k1] = pb[k1];
+        }
+        if (k2 == 0)
+        {
+            pra[128] = pa[8]; prb[128] = pb[8]; pra[129] = 0.0f; prb[129] = 0.0f;
+            s_e[fq + 2 * f] = rawe2.x; s_e[fq + 2 * f + 1] = rawe2.y;
+        }
+    }
+    else
+    {
+        float *pr = s_pow + (fq + f) * PPK;
+        if (p.amp)
+        {
+#pragma unroll
+            for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+        {
+            pr[k2 + 16 * k1] = pa[k1];
+            pr[NC - k2 - 16 * k1] = pb[k1];
+        }
+        if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }       // column 257: the zero a padded k-loop may touch
+    }
+    __syncthreads();
+
+    // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
+    const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
+    const int fr0 = (lane >> 4) * 4, col = lane & 15;
+    for (int job = wv; job < RTK * p.ntile_m; job += MW)
+    {
+        const int t = job / RTK, rt = job - t * RTK;                          // mel tile, 16-frame row tile
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * p.mel_ksteps[t], BUF_FLAGS);
+        const f32x4 acc = mfma_tile4(s_pow + (16 * rt + col) * PPK + p.mel_kbeg[t] + (lane >> 4), rb, lane * 4, p.mel_ksteps[t]);
+        const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
+        const bool live = col < p.mel_cnt[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const int fr = 16 * rt + fr0 + r;
+            const float v = acc[r];
+            if (KIND == SPEECH_FBANK)
+            {
+                if (live) { s_out[fr * p.D + eo + m] = p.lg ? floor_log(v) : v; }           // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column)
+            }
+            else if (KIND == SPEECH_MFCC)
+            {
+                if (live) { s_mel[fr * p.MP + m] = floor_log(v); }                          // c/kaldi_mfcc.c:318
+            }
+            else
+            {
+                // equal loudness, compression, end duplication (c/kaldi_plp.c:339-358)
+                if (live)
+                {
+                    const float x = v * p.aux[m];
+                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : __builtin_amdgcn_exp2f(p.compress * __log2f(x)));
+                    s_mel[fr * p.MP + 1 + m] = c;
+                    if (m == 0) { s_mel[fr * p.MP] = c; }
+                    if (m == p.B - 1) { for (int j = p.B + 1; j < p.K2; ++j) { s_mel[fr * p.MP + j] = (j == p.B + 1) ? c : 0.0f; } }
+                }
+            }
+        }
+    }
+    if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
+    if (KIND == SPEECH_MFCC && tid < 4 * TILEK) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
+    __syncthreads();
+
+    if (KIND == SPEECH_MFCC)
+    {
+        // DCT-II x lifter as a second contraction (c/kaldi_mfcc.c:323-333); the last-cepstrum quirk is a duplicated column
+        for (int job = wv; job < RTK * p.ntile_c; job += MW)
+        {
+            const int t = job / RTK, rt = job - t * RTK;
+            const f32x4 acc = mfma_tile(s_mel + (16 * rt + col) * p.MP + (lane >> 4), p.mat2 + (lane >> 4) * p.Cp + 16 * t + col, 4 * p.Cp, p.K2 >> 2);
+            const int c = 16 * t + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int fr = 16 * rt + fr0 + r;
+                if (c < p.C) { s_out[fr * p.C + c] = (p.use_energy && c == 0) ? pos_log(s_e[fr]) : acc[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    if (KIND == SPEECH_PLP)
+    {
+        // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames
+        if (wv < RTK)
+        {
+            const f32x4 acc = mfma_tile(s_mel + (16 * wv + col) * p.MP + (lane >> 4), p.mat2 + lane, 64, p.K2 >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s_ac[(16 * wv + fr0 + r) * 17 + col] = acc[r]; }
+        }
+        __syncthreads();
+        if (tid < TILEK)
+        {
+            // one lane per frame: Levinson-Durbin with Kaldi's 1 - k^2 >= 1e-5 guard, LPC -> cepstrum, lifter
+            // (reference intent c/kaldi_plp.c:206,380-403)
+            const float *r = s_ac + tid * 17;
+            float a[P > 0 ? P : 1], tmp[P > 0 ? P : 1], cep[P > 0 ? P : 1];
+            float E = r[0];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                float ki = r[i + 1];
+#pragma unroll
+                for (int j = 0; j < i; ++j) { ki += a[j] * r[i - j]; }
+                ki = ki / E;
+                float c = 1.0f - ki * ki;
+                c = (c < 1.0e-5f) ? 1.0e-5f : c;
+                E *= c;
+                tmp[i] = -ki;
+#pragma unroll
+                for (int j = 0; j < i; ++j) { tmp[j] = a[j] - ki * a[i - j - 1]; }
+#pragma unroll
+                for (int j = 0; j <= i; ++j) { a[j] = tmp[j]; }
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < i; ++j) { sum += (float)(i - j) * a[j] * cep[i - j - 1]; }
+                cep[i] = -a[i] - sum / (float)(i + 1);
+            }
+            const float *lift = p.aux + p.B;
+            float *y = s_out + tid * p.C;
+            const int C = p.C;
+            float prev = 0.0f;
+#pragma unroll
+            for (int k = 0; k <= P; ++k)
+            {
+                if (k < C)
+                {
+                    float v = (k == 0) ? floor_log(E) : cep[k > 0 ? k - 1 : 0];
+                    v *= lift[k];
+                    if (k == 0 && p.use_energy) { v = pos_log(s_e[tid]); }     // c/kaldi_plp.c:397
+                    if (k == C - 1 && C >= 2) { v = prev; }                                               // c/kaldi_plp.c:403
+                    y[k] = v; prev = v;
+                }
+            }
+            for (int k = P + 1; k < C; ++k) { const float v = (k == C - 1) ? prev : 0.0f; y[k] = v; prev = v; }
+        }
+        __syncthreads();
+    }
+
+    // the tile's nframes x D outputs are one contiguous run of Y
+    float *y = p.Y + utt.y_off + (unsigned long long)tile.frame0 * (unsigned long long)p.D;
+    const int nout = (int)tile.nframes * p.D;
+    for (int i = tid; i < nout; i += NTM) { y[i] = s_out[i]; }
+}
+
+template <int NZ, bool DITHER, bool PAIR>
+kernel_fn mel_for_kind(int kind)
+{
+    switch (kind)
+    {
+        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER, PAIR>;
+        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER, PAIR>;
+        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER, PAIR>;
+    }
+}
+
+// dithered frames have their own instantiations: the generator's temporaries would otherwise cost the plain kernels
+// 13-24 VGPRs and a resident workgroup per CU
+template <bool PAIR>
+kernel_fn mel_for_nz(int nz, int kind, bool dither)
+{
+    switch (nz)
+    {
+        case 9: return dither ? mel_for_kind<9, true, PAIR>(kind) : mel_for_kind<9, false, PAIR>(kind);
+        case 10: return dither ? mel_for_kind<10, true, PAIR>(kind) : mel_for_kind<10, false, PAIR>(kind);
+        case 11: return dither ? mel_for_kind<11, true, PAIR>(kind) : mel_for_kind<11, false, PAIR>(kind);
+        case 12: return dither ? mel_for_kind<12, true, PAIR>(kind) : mel_for_kind<12, false, PAIR>(kind);
+        case 13: return dither ? mel_for_kind<13, true, PAIR>(kind) : mel_for_kind<13, false, PAIR>(kind);
+        case 14: return dither ? mel_for_kind<14, true, PAIR>(kind) : mel_for_kind<14, false, PAIR>(kind);
+        case 15: return dither ? mel_for_kind<15, true, PAIR>(kind) : mel_for_kind<15, false, PAIR>(kind);
+        default: return dither ? mel_for_kind<16, true, PAIR>(kind) : mel_for_kind<16, false, PAIR>(kind);
+    }
+}
+
+}  // namespace
+
+kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair)
+{
+    return pair ? mel_for_nz<true>(nz, kind, dither) : mel_for_nz<false>(nz, kind, dither);
+}
+
+}  // namespace speech
