@@ -15,6 +15,10 @@
 // ("<utt-id> \0B" "FM " \4 <int32 rows> \4 <int32 cols> <rows x cols floats>, "DM " for double -- the layout the
 // reference's kaldi2bin scans for, src/kaldi2bin.cpp:141-175), --append adds it to an existing archive, and
 // --scp=<file> appends the matching "<utt-id> <ark>:<offset>" line, so the tools can stand in for compute-mfcc-feats.
+// Widening: an input that starts with "RIFF" is read as a 16-bit PCM WAVE file (--channel=<n> picks the
+// channel, default 0); the samples go to the device as int16 (speech_extract_pcm16, include/speech_hip.h) and keep their
+// integer scale, as Kaldi's wave reader leaves them.  The sample rate comes from the header unless -r is given, and an
+// -r that contradicts the header is an error.  The output is float32.
 #include <cctype>
 #include <cfloat>
 #include <cstdint>
@@ -29,6 +33,7 @@
 #include <unistd.h>
 #include <vector>
 #include "../include/codee_speech.h"
+#include "../include/speech_hip.h"
 
 #define TOOL_SPECTROGRAM 0
 #define TOOL_FBANK 1
@@ -55,10 +60,9 @@ static int fail(int line, const string &msg)
 struct NpyInfo { bool f64 = false, fortran = false; vector<size_t> shape; size_t n = 0; };
 
 // .npy v1/v2/v3 header (public format): magic, version, little-endian header length, python dict literal
-static bool read_npy_header(istream &is, NpyInfo &h)
+static bool read_npy_header(istream &is, NpyInfo &h, const char magic[8])
 {
-    char magic[8];
-    if (!is.read(magic, 8) || memcmp(magic, "\x93NUMPY", 6) != 0) { return false; }
+    if (memcmp(magic, "\x93NUMPY", 6) != 0) { return false; }
     size_t hlen = 0;
     if (magic[6] == 1) { unsigned char b[2]; if (!is.read((char *)b, 2)) { return false; } hlen = b[0] | (b[1] << 8); }
     else { unsigned char b[4]; if (!is.read((char *)b, 4)) { return false; } hlen = b[0] | (b[1] << 8) | (b[2] << 16) | ((size_t)b[3] << 24); }
@@ -90,6 +94,49 @@ static bool read_npy_header(istream &is, NpyInfo &h)
     return true;
 }
 
+// RIFF/WAVE, 16-bit PCM (public format).  `magic` holds the first 8 bytes ("RIFF" + size).  Reads up to the end of the data
+// chunk (or of the stream when the chunk size is 0 or 0xFFFFFFFF, as streamed files have it) and returns one channel.
+struct WavInfo { unsigned channels = 0, rate = 0; vector<short> x; };
+static bool read_wav(istream &is, const char magic[8], unsigned channel, WavInfo &w, string &why)
+{
+    auto u16 = [](const unsigned char *b) { return (unsigned)(b[0] | (b[1] << 8)); };
+    auto u32 = [](const unsigned char *b) { return (unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16) | ((unsigned)b[3] << 24); };
+    unsigned char b[40];
+    if (memcmp(magic, "RIFF", 4) != 0 || !is.read((char *)b, 4) || memcmp(b, "WAVE", 4) != 0) { why = "not a RIFF/WAVE file"; return false; }
+    bool have_fmt = false;
+    for (;;)
+    {
+        if (!is.read((char *)b, 8)) { why = "no data chunk"; return false; }
+        const unsigned size = u32(b + 4);
+        if (memcmp(b, "fmt ", 4) == 0)
+        {
+            if (size < 16 || size > 40 || !is.read((char *)b, size)) { why = "bad fmt chunk"; return false; }
+            unsigned tag = u16(b);
+            if (tag == 0xFFFEu && size >= 26) { tag = u16(b + 24); }                         // WAVE_FORMAT_EXTENSIBLE: first two bytes of the sub-format
+            w.channels = u16(b + 2); w.rate = u32(b + 4);
+            if (tag != 1u || u16(b + 14) != 16u) { why = "only 16-bit PCM is supported"; return false; }
+            if (w.channels < 1u || u16(b + 12) != 2u * w.channels) { why = "bad channel count or block size"; return false; }
+            if (size & 1u) { is.ignore(1); }
+            have_fmt = true;
+        }
+        else if (memcmp(b, "data", 4) == 0)
+        {
+            if (!have_fmt) { why = "data chunk before fmt chunk"; return false; }
+            if (channel >= w.channels) { why = "channel not in file"; return false; }
+            const bool open_ended = (size == 0u || size == 0xFFFFFFFFu);
+            const size_t frame = 2u * w.channels;
+            vector<unsigned char> buf;
+            if (open_ended) { buf.assign(istreambuf_iterator<char>(is), istreambuf_iterator<char>()); }
+            else { buf.resize(size); is.read((char *)buf.data(), (streamsize)size); buf.resize((size_t)is.gcount()); }     // a truncated file gives what it holds
+            const size_t n = buf.size() / frame;
+            w.x.resize(n);
+            for (size_t i = 0; i < n; ++i) { w.x[i] = (short)u16(buf.data() + i * frame + 2u * channel); }
+            return true;
+        }
+        else { is.ignore((streamsize)size + (size & 1u)); if (!is) { why = "no data chunk"; return false; } }
+    }
+}
+
 static bool write_npy_header(ostream &os, bool f64, bool fortran, size_t r, size_t c)
 {
     string d = string("{'descr': '") + (f64 ? "<f8" : "<f4") + "', 'fortran_order': " + (fortran ? "True" : "False") + ", 'shape': (" + to_string(r) + ", " + to_string(c) + "), }";
@@ -108,7 +155,7 @@ static void usage()
     if (TOOL == TOOL_PLP) { cout << " [--compress=<dbl>] [--cep_scale=<dbl>]"; }
     cout << " [-m] [-o <file>] [-h]\n\n";
     const char *fmt = "  %-25s %s\n";
-    printf(fmt, "<file>", "input file (X), .npy float32/float64 vector; stdin if absent or -");
+    printf(fmt, "<file>", "input file (X), .npy float32/float64 vector or 16-bit PCM .wav; stdin if absent or -");
     printf(fmt, "-r, --srate=<dbl>", "sample rate in Hz [default=16000.0]");
     printf(fmt, "-t, --frame_length=<dbl>", "length in ms of each frame [default=25]");
     printf(fmt, "-s, --frame_shift=<dbl>", "step in ms between each frame [default=10]");
@@ -142,6 +189,7 @@ static void usage()
     printf(fmt, "--ark=<utt-id>", "write Y as a Kaldi binary archive entry with this key instead of .npy");
     printf(fmt, "--append", "with --ark: append to the archive instead of replacing it");
     printf(fmt, "--scp=<file>", "with --ark and -o: append \"<utt-id> <ofile>:<offset>\" to this script file");
+    printf(fmt, "--channel=<n>", "with a .wav input: the channel to use [default=0]");
     printf(fmt, "-h, --help", "display this help and exit");
     cout << "\nMakes Kaldi " << (TOOL == TOOL_SPECTROGRAM ? "spectrogram" : TOOL == TOOL_FBANK ? "mel-fbank" : TOOL == TOOL_MFCC ? "MFCC" : "PLP")
          << " features for univariate, real-valued X on an AMD MI355X (libspeech.so).\n"
@@ -155,10 +203,10 @@ static void usage()
 int main(int argc, char *argv[])
 {
     double sr = 16000.0, fl = 25.0, shft = 10.0, d = 0.1, p = 0.97, lof = 20.0, hif = 0.0, Q = 22.0, compress = 1.0 / 3.0, cep_scale = 1.0;
-    long Bi = 23, Ci = 13;
+    long Bi = 23, Ci = 13, channel = 0;
     int snipe = 0, dc0 = 0, rawe = 0, amp = 0, lg = 0, usee = 0, mn0 = 0, help = 0;
     string wintype = "povey", ofile, ark_key, scp_file;
-    bool have_o = false, append = false;
+    bool have_o = false, append = false, have_r = false;
 
     static const option longopts[] = {
         {"srate", required_argument, nullptr, 'r'}, {"frame_length", required_argument, nullptr, 't'}, {"frame_shift", required_argument, nullptr, 's'},
@@ -168,7 +216,7 @@ int main(int argc, char *argv[])
         {"B", required_argument, nullptr, 'b'}, {"log", no_argument, nullptr, 'g'}, {"C", required_argument, nullptr, 'c'}, {"Q", required_argument, nullptr, 'q'},
         {"use_energy", no_argument, nullptr, 'x'}, {"zero_mean", no_argument, nullptr, 'm'}, {"ofile", required_argument, nullptr, 'o'},
         {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001},
-        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {nullptr, 0, nullptr, 0}};
+        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {nullptr, 0, nullptr, 0}};
     const char *shortopts = TOOL == TOOL_SPECTROGRAM ? "r:t:s:ed:zyp:w:mo:h" : TOOL == TOOL_FBANK ? "r:t:s:ed:zyp:w:al:u:b:gxmo:h" : "r:t:s:ed:zyp:w:l:u:b:c:q:xmo:h";
     int c, nerrs = 0;
     opterr = 0;
@@ -178,7 +226,7 @@ int main(int argc, char *argv[])
         auto num = [&](double &v) { v = strtod(optarg, &end); if (end == optarg || *end) { ++nerrs; cerr << prog() << ": invalid argument \"" << optarg << "\" to option" << endl; } };
         switch (c)
         {
-            case 'r': num(sr); break; case 't': num(fl); break; case 's': num(shft); break; case 'e': snipe = 1; break;
+            case 'r': num(sr); have_r = true; break; case 't': num(fl); break; case 's': num(shft); break; case 'e': snipe = 1; break;
             case 'd': num(d); break; case 'z': dc0 = 1; break; case 'y': rawe = 1; break; case 'p': num(p); break;
             case 'w': wintype = optarg; break; case 'a': amp = 1; break; case 'l': num(lof); break; case 'u': num(hif); break;
             case 'b': Bi = strtol(optarg, &end, 10); if (end == optarg || *end) { ++nerrs; } break;
@@ -191,6 +239,7 @@ int main(int argc, char *argv[])
             case 1002: ark_key = optarg; break;
             case 1003: scp_file = optarg; break;
             case 1004: append = true; break;
+            case 1005: channel = strtol(optarg, &end, 10); if (end == optarg || *end || channel < 0) { ++nerrs; } break;
             default: ++nerrs; cerr << prog() << ": invalid option \"" << argv[optind - 1] << "\"" << endl; break;
         }
     }
@@ -209,7 +258,19 @@ int main(int argc, char *argv[])
     if (!stdi1) { ifs1.open(ifile, ios::binary); if (!ifs1) { FAIL("problem opening input file"); } }
     istream &is = stdi1 ? cin : ifs1;
     NpyInfo i1;
-    if (!read_npy_header(is, i1)) { FAIL("problem reading header for input file"); }
+    WavInfo wav;
+    char magic[8];
+    if (!is.read(magic, 8)) { FAIL("problem reading header for input file"); }
+    const bool is_wav = memcmp(magic, "RIFF", 4) == 0;
+    if (is_wav)
+    {
+        string why;
+        if (!read_wav(is, magic, (unsigned)channel, wav, why)) { FAIL("problem reading .wav input: " + why); }
+        if (have_r && sr != (double)wav.rate) { FAIL("srate (sample rate) does not match the .wav header (" + to_string(wav.rate) + " Hz)"); }
+        sr = (double)wav.rate;
+        i1.f64 = false; i1.fortran = false; i1.shape.assign(1, wav.x.size()); i1.n = wav.x.size();
+    }
+    else if (!read_npy_header(is, i1, magic)) { FAIL("problem reading header for input file"); }
     if (TOOL == TOOL_FBANK && i1.f64) { FAIL("input data type must be in {1}"); }            // srci/kaldi_fbank.cpp:6
 
     // options: src/kaldi_mfcc.cpp:179-246
@@ -278,7 +339,20 @@ int main(int argc, char *argv[])
     timespec tic, toc;
     clock_gettime(CLOCK_REALTIME, &tic);
     int rc;
-    if (!i1.f64)
+    if (is_wav)
+    {
+        speech_opts o;
+        speech_opts_default(&o, TOOL == TOOL_SPECTROGRAM ? SPEECH_SPECTROGRAM : TOOL == TOOL_FBANK ? SPEECH_FBANK : TOOL == TOOL_MFCC ? SPEECH_MFCC : SPEECH_PLP);
+        o.dtype = SPEECH_F32; o.sr = sr; o.frame_length = fl; o.frame_shift = shft; o.snip_edges = snipe; o.dither = d; o.dc0 = dc0; o.raw_energy = rawe;
+        o.preemph = p; o.mn0 = mn0; o.amp = amp; o.lof = lof; o.hif = hif; o.B = B; o.lg = lg; o.use_energy = usee; o.C = C; o.Q = Q;
+        o.compress = compress; o.cep_scale = cep_scale; o.lpc_order = 0;
+        strncpy(o.win_type, wintype.c_str(), sizeof(o.win_type) - 1); o.win_type[sizeof(o.win_type) - 1] = '\0';
+        vector<float> Y(W * D + 1);
+        rc = speech_extract_pcm16(&o, wav.x.data(), N, Y.data());
+        if (rc) { FAIL("problem during function call"); }
+        if (wo1 && !os.write((const char *)Y.data(), (streamsize)(W * D * sizeof(float)))) { FAIL("problem writing output file (Y)"); }
+    }
+    else if (!i1.f64)
     {
         vector<float> X(N), Y(W * D + 1);
         if (!is.read((char *)X.data(), (streamsize)(N * sizeof(float)))) { FAIL("problem reading input file (X)"); }

@@ -87,6 +87,12 @@ int speech_batch_run_timed(speech_batch *batch, const void *X_dev, void *Y_dev, 
    input bytes over PCIe and HBM.  kernel_ms may be NULL (asynchronous) or receives the per-frame kernel's duration. */
 int speech_batch_run_pcm16(speech_batch *batch, const short *X16_dev, void *Y_dev, void *stream, float *kernel_ms);
 
+/* The same widening for host callers: one utterance of 16-bit PCM in host memory -> features in host memory (opts->dtype),
+   exactly as a drop-in call of include/codee_speech.h with these options would return them for the converted audio
+   (validation, error style, plan cache, staging buffers), with half the bytes over PCIe.  Y must hold W x D elements
+   (speech_plan_num_frames / the reference's W formula, c/kaldi_mfcc.c:77). */
+int speech_extract_pcm16(const speech_opts *opts, const short *X16_host, size_t N, void *Y_host);
+
 /* Widening: corpus post-processing on a batch's packed features Y_dev (frame-major W x D per utterance,
    the layout speech_batch_run writes).  The reference's only post-pass is mn0, the per-utterance mean subtraction
    (c/kaldi_fbank.c:355-370, c/kaldi_mfcc.c:337-352); these generalise it to Kaldi's apply-cmvn, add-deltas and
@@ -102,12 +108,19 @@ int speech_batch_run_pcm16(speech_batch *batch, const short *X16_dev, void *Y_de
    - add_deltas: Z[t] = [Y[t] | delta | delta-delta | ...], D (order + 1) columns, order in [0 3], window in [1 5], filters
      and edge clamping as Kaldi's DeltaFeatures; utterance u of Z starts at (order + 1) x its offset in Y.
    - splice: Z[t] = [Y[t-left] | ... | Y[t+right]] with the frame index clamped to the utterance, D (left + right + 1)
-     columns; utterance u of Z starts at (left + right + 1) x its offset in Y.  Z must not alias Y. */
+     columns; utterance u of Z starts at (left + right + 1) x its offset in Y.  Z must not alias Y.
+   - splice_subsample: splice-feats followed by subsample-feats --n=n --offset=offset in one pass (left = right = 0: the
+     subsampling alone): row j of an utterance's output is its spliced frame offset + j n, ceil((W - offset) / n) rows (none
+     if W <= offset); n >= 1, 0 <= offset < n.  The utterances' outputs are packed back to back in batch order;
+     speech_batch_subsample_rows gives the rows per utterance (rows may be NULL) and their total.  The first call with a
+     new (n, offset) waits for the stream and uploads a table of nutt offsets; later calls only launch. */
 int speech_batch_stats(speech_batch *batch, const void *Y_dev, double *sum, double *sumsq, unsigned long long *frames, void *stream);
 int speech_batch_cmvn(speech_batch *batch, void *Y_dev, int norm_vars, void *stream);
 int speech_batch_affine(speech_batch *batch, void *Y_dev, const double *scale, const double *offset, void *stream);
 int speech_batch_add_deltas(speech_batch *batch, const void *Y_dev, void *Z_dev, int order, int window, void *stream);
 int speech_batch_splice(speech_batch *batch, const void *Y_dev, void *Z_dev, int left, int right, void *stream);
+int speech_batch_splice_subsample(speech_batch *batch, const void *Y_dev, void *Z_dev, int left, int right, int n, int offset, void *stream);
+int speech_batch_subsample_rows(const speech_batch *batch, int n, int offset, size_t *rows, size_t *total_rows);
 
 #ifdef __cplusplus
 }

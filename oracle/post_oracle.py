@@ -3,7 +3,7 @@ never by the product path.
 
 PARITY UNPINNED: the reference has only mn0 (c/kaldi_fbank.c:355-370), and that with a stride defect (SURVEY.md 8(a)
 row N); CMVN, deltas and splicing restate the published behaviour of Kaldi's apply-cmvn, add-deltas (DeltaFeatures in
-feature-functions.cc) and splice-feats, which are not in /root/reference.  Plain numpy, one utterance (W x D) at a time.
+feature-functions.cc), splice-feats and subsample-feats, which are not in /root/reference.  Plain numpy, one utterance (W x D) at a time.
 """
 import numpy as np
 
@@ -56,3 +56,8 @@ def add_deltas(y, order=2, window=2):
 def splice(y, left, right):
     W, D = y.shape
     return np.concatenate([y[np.clip(np.arange(W) + c, 0, W - 1)] for c in range(-left, right + 1)], axis=1)
+
+
+def subsample(y, n, offset=0):
+    """Kaldi subsample-feats --n=n --offset=offset (n > 0): frames offset, offset + n, ..."""
+    return y[offset::n]

@@ -104,6 +104,24 @@ def make_opts(kind, dtype="f32", **kw):
     return o
 
 
+def extract_pcm16(kind, X16, dtype="f32", **kw):
+    """One utterance of 16-bit PCM (numpy int16, host) -> features, as the drop-in call on the converted audio returns
+    them; half the bytes cross PCIe (speech_extract_pcm16, include/speech_hip.h).  Options as make_opts."""
+    lib = _lib.load()
+    o = make_opts(kind, dtype, **kw)
+    X16 = np.ascontiguousarray(X16)
+    if X16.dtype != np.int16:
+        raise TypeError("X16 must be int16")
+    X16 = X16.reshape(-1)
+    t = np.float64 if o.dtype == _lib.F64 else np.float32
+    W, L, _ = frame_sizes(X16.size, o.sr, o.frame_length, o.frame_shift, o.snip_edges, t)
+    D = {"spectrogram": _nfft(max(L, 1)) // 2 + 1, "fbank": o.B + (1 if o.use_energy else 0)}.get(kind, o.C)
+    Y = np.zeros((max(W, 1), D), dtype=t)
+    if lib.speech_extract_pcm16(C.byref(o), X16.ctypes.data_as(C.POINTER(C.c_short)), X16.size, Y.ctypes.data_as(C.c_void_p)) != 0:
+        raise SpeechError(_lib.last_error() or "speech_extract_pcm16 failed")
+    return Y[:W]
+
+
 class Plan:
     """speech_plan: the per-call tables of c/kaldi_mfcc.c:105-210, built once on one device."""
 
@@ -227,6 +245,18 @@ class Batch:
         """Z (total_out * (left + right + 1) elements) = frames spliced with their neighbours, Kaldi splice-feats"""
         self._check(self._lib.speech_batch_splice(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(left), int(right),
                                                   C.c_void_p(stream) if stream else None))
+
+    def subsample_rows(self, n, offset=0):
+        """(rows per utterance, total rows) of splice_subsample's output for --n=n --offset=offset"""
+        rows, tot = (C.c_size_t * max(1, self.nutt))(), C.c_size_t()
+        self._check(self._lib.speech_batch_subsample_rows(self._h, int(n), int(offset), rows, C.byref(tot)))
+        return np.array(rows[:self.nutt], dtype=np.int64), int(tot.value)
+
+    def splice_subsample(self, Y, Z, left=0, right=0, n=3, offset=0, stream=None):
+        """Z (subsample_rows(n, offset)[1] * D * (left + right + 1) elements, utterances back to back) = every n-th spliced
+        frame from `offset`: Kaldi splice-feats | subsample-feats in one pass"""
+        self._check(self._lib.speech_batch_splice_subsample(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(left), int(right),
+                                                            int(n), int(offset), C.c_void_p(stream) if stream else None))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -2,9 +2,11 @@
 //
 // The reference's only post-pass is mn0, the per-utterance mean subtraction (c/kaldi_fbank.c:355-370); these kernels
 // generalise it to what Kaldi recipes run after feature extraction: cepstral mean / variance normalisation per utterance
-// or with corpus-wide statistics (apply-cmvn), delta features (add-deltas) and frame splicing (splice-feats).  All are
+// or with corpus-wide statistics (apply-cmvn), delta features (add-deltas), frame splicing (splice-feats) and frame
+// subsampling (subsample-feats, fused with the splice).  All are
 // HBM-bound passes over frame-major W x D matrices packed back to back: consecutive lanes touch consecutive floats.
 #include "speech_internal.hpp"
+#include <type_traits>
 
 namespace speech {
 namespace {
@@ -40,6 +42,20 @@ __global__ __launch_bounds__(NT) void utt_moments_kernel(const PostParams p)
             mom[c0 + tid] = s; mom[p.D + c0 + tid] = q;
         }
         __syncthreads();
+    }
+}
+
+// Sums of groups of POST_REDUCE_GROUP consecutive rows of a [n][cols] array of doubles, each group added in row order:
+// the corpus-wide statistics as a tree of fixed shape over the utterances, the same sums on every run.
+__global__ __launch_bounds__(NT) void reduce_rows_kernel(const double *__restrict__ in, double *__restrict__ out, unsigned long long n, int cols)
+{
+    const unsigned long long u0 = (unsigned long long)blockIdx.x * POST_REDUCE_GROUP;
+    const int cnt = (int)min((unsigned long long)POST_REDUCE_GROUP, n - u0);
+    for (int c = threadIdx.x; c < cols; c += NT)
+    {
+        double s = 0.0;
+        for (int k = 0; k < cnt; ++k) { s += in[(u0 + k) * cols + c]; }
+        out[(unsigned long long)blockIdx.x * cols + c] = s;
     }
 }
 
@@ -91,62 +107,156 @@ __global__ __launch_bounds__(NT) void utt_affine_kernel(const PostParams p)
 
 // add-deltas: Z[t] = [ Y[t] | delta | delta-delta ... ], order k uses the k-fold convolution of the window
 // [-w..w] / sum(j^2) with itself, evaluated on the input with the frame index clamped to the utterance
-// (Kaldi feature-functions.cc, DeltaFeatures::Process).
-template <typename T>
+// (Kaldi feature-functions.cc, DeltaFeatures::Process).  A workgroup takes rows_per_wg frames; a thread walks the chunk's
+// elements (frame r, column d, kept incrementally: no division per element), reads the 2 order window + 1 neighbouring
+// frames once (consecutive lanes on consecutive floats; the re-reads hit the caches) and feeds every order's filter from
+// them, each order summing its taps in ascending order.
+// ORDER, WINDOW >= 0: fixed at compile time (Kaldi's default 2, 2): the neighbouring frames' loads are issued together and
+// the filter loops unroll; ORDER < 0: any order / window from the arguments, one frame at a time.
+template <typename T, int ORDER, int WINDOW>
 __global__ __launch_bounds__(NT) void add_deltas_kernel(const PostParams p)
 {
+    __shared__ T taps[POST_MAX_ORDER + 1][POST_MAX_TAPS + 1];              // the filters in T: the kernel arguments hold them in double
     const UttDesc utt = p.utts[blockIdx.x];
     const long long W = (long long)utt.W;
     const long long row0 = (long long)blockIdx.y * p.rows_per_wg;
     if (row0 >= W) { return; }
-    const long long rows = min((long long)p.rows_per_wg, W - row0);
-    const T *y = reinterpret_cast<const T *>(p.Yin) + utt.y_off;
-    const int K = p.order + 1, Dz = p.D * K;
-    T *z = reinterpret_cast<T *>(p.Y) + utt.y_off * (unsigned long long)K;
-    const long long n = rows * p.D;
-    for (long long i = threadIdx.x; i < n; i += NT)
+    for (int i = threadIdx.x; i < (POST_MAX_ORDER + 1) * POST_MAX_TAPS; i += NT) { taps[i / POST_MAX_TAPS][i % POST_MAX_TAPS] = (T)p.dscale[i / POST_MAX_TAPS][i % POST_MAX_TAPS]; }
+    __syncthreads();
+    constexpr bool FIXED = ORDER >= 0;
+    const int order = FIXED ? ORDER : p.order, window = FIXED ? WINDOW : p.window;
+    const int rows = (int)min((long long)p.rows_per_wg, W - row0);
+    const int D = p.D, K = order + 1, Dz = D * K, maxhalf = order * window;
+    const T *__restrict__ y0 = reinterpret_cast<const T *>(p.Yin) + utt.y_off + (unsigned long long)row0 * D;
+    T *__restrict__ z0 = reinterpret_cast<T *>(p.Y) + utt.y_off * (unsigned long long)K + (unsigned long long)row0 * Dz;
+    // frame index relative to row0, clamped to the utterance (the bounds only matter within maxhalf of the chunk)
+    const int lo = (int)max(-row0, (long long)-64), hi = (int)min(W - 1 - row0, (long long)rows + 64);
+    const int n = rows * D, rstep = NT / D, dstep = NT % D;
+    int r = (int)threadIdx.x / D, d = (int)threadIdx.x - r * D;
+    for (int i = threadIdx.x; i < n; i += NT)
     {
-        const long long t = row0 + i / p.D;
-        const int d = (int)(i % p.D);
-        for (int k = 0; k < K; ++k)
+        T acc[POST_MAX_ORDER + 1];
+#pragma unroll
+        for (int k = 0; k <= POST_MAX_ORDER; ++k) { acc[k] = (T)0; }
+        if (FIXED)
         {
-            const int half = k * p.window;
-            T acc = (T)0;
-            for (int j = -half; j <= half; ++j)
+            constexpr int MH = FIXED ? ORDER * WINDOW : 0;
+            T v[2 * MH + 1];
+#pragma unroll
+            for (int j = -MH; j <= MH; ++j) { v[j + MH] = y0[min(max(r + j, lo), hi) * D + d]; }
+#pragma unroll
+            for (int j = -MH; j <= MH; ++j)
             {
-                long long tt = t + j;
-                tt = tt < 0 ? 0 : (tt >= W ? W - 1 : tt);
-                acc = fma((T)p.dscale[k][j + half], y[tt * p.D + d], acc);
+#pragma unroll
+                for (int k = 0; k <= (FIXED ? ORDER : 0); ++k)
+                {
+                    if ((j < 0 ? -j : j) <= k * WINDOW) { acc[k] = fma(taps[k][j + k * WINDOW], v[j + MH], acc[k]); }
+                }
             }
-            z[t * Dz + k * p.D + d] = acc;
+        }
+        else
+        {
+            for (int j = -maxhalf; j <= maxhalf; ++j)
+            {
+                const T v = y0[min(max(r + j, lo), hi) * D + d];
+                const int aj = j < 0 ? -j : j;
+#pragma unroll
+                for (int k = 0; k <= POST_MAX_ORDER; ++k)
+                {
+                    if (k < K && aj <= k * window) { acc[k] = fma(taps[k][j + k * window], v, acc[k]); }
+                }
+            }
+        }
+        T *zr = z0 + (size_t)r * Dz + d;
+#pragma unroll
+        for (int k = 0; k <= POST_MAX_ORDER; ++k) { if (k < K) { zr[k * D] = acc[k]; } }
+        r += rstep; d += dstep;
+        if (d >= D) { d -= D; ++r; }
+    }
+}
+
+// splice-feats: Z[t] = [ Y[t-left] | ... | Y[t] | ... | Y[t+right] ], frame index clamped to the utterance; SUB: followed by
+// subsample-feats in the same pass (output row j of an utterance is the spliced frame sub_off + j sub_n; the utterances'
+// outputs packed back to back, zrow[u] = rows of the utterances before u).
+// Away from the utterance's ends a spliced row is one contiguous run of Y: (left + right + 1) D elements from frame
+// t - left on, so the pass is a copy with overlapping sources.  E is the unit of that copy: T, or 16 bytes of T when D and
+// the utterance offsets allow it.  One wave per output row (several rows per wave when a row is shorter than 64 units).
+template <typename E, bool SUB>
+__device__ __forceinline__ void splice_rows(const PostParams &p, int D, unsigned long long y_off, unsigned long long z_off)
+{
+    const UttDesc utt = p.utts[blockIdx.x];
+    const long long W = (long long)utt.W;
+    const long long Wz = !SUB ? W : (W > p.sub_off ? (W - p.sub_off + p.sub_n - 1) / p.sub_n : 0);
+    const long long row0 = (long long)blockIdx.y * p.rows_per_wg;
+    if (row0 >= Wz) { return; }
+    const int rows = (int)min((long long)p.rows_per_wg, Wz - row0);
+    const int K = p.left + p.right + 1, Dz = D * K;
+    const E *y = reinterpret_cast<const E *>(p.Yin) + y_off;
+    E *z = reinterpret_cast<E *>(p.Y) + z_off + (unsigned long long)row0 * Dz;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rpw = Dz >= 64 ? 1 : 64 / Dz;                                  // rows per wave and pass
+    const int lr = Dz >= 64 ? 0 : lane / Dz, lc = lane - lr * Dz;
+    if (lr >= rpw) { return; }
+    for (int r = wave * rpw + lr; r < rows; r += (NT / 64) * rpw)
+    {
+        const long long t = SUB ? (long long)p.sub_off + (row0 + r) * p.sub_n : row0 + r;
+        E *zr = z + (size_t)r * Dz;
+        if (t - p.left >= 0 && t + p.right < W)
+        {
+            const E *src = y + (t - p.left) * D;
+            for (int c = lc; c < Dz; c += 64) { zr[c] = src[c]; }
+        }
+        else
+        {
+            for (int c = lc; c < Dz; c += 64)
+            {
+                const int k = c / D;
+                long long tt = t + k - p.left;
+                tt = tt < 0 ? 0 : (tt >= W ? W - 1 : tt);
+                zr[c] = y[tt * D + (c - k * D)];
+            }
         }
     }
 }
 
-// splice-feats: Z[t] = [ Y[t-left] | ... | Y[t] | ... | Y[t+right] ], frame index clamped to the utterance
-template <typename T>
+template <typename T, bool SUB, bool VEC>
 __global__ __launch_bounds__(NT) void splice_kernel(const PostParams p)
 {
     const UttDesc utt = p.utts[blockIdx.x];
-    const long long W = (long long)utt.W;
-    const long long row0 = (long long)blockIdx.y * p.rows_per_wg;
-    if (row0 >= W) { return; }
-    const long long rows = min((long long)p.rows_per_wg, W - row0);
-    const T *y = reinterpret_cast<const T *>(p.Yin) + utt.y_off;
-    const int K = p.left + p.right + 1, Dz = p.D * K;
-    T *z = reinterpret_cast<T *>(p.Y) + utt.y_off * (unsigned long long)K + (unsigned long long)row0 * Dz;
-    const long long n = rows * Dz;
-    for (long long i = threadIdx.x; i < n; i += NT)
+    const unsigned long long K = (unsigned long long)(p.left + p.right + 1);
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef typename std::conditional<sizeof(T) == 4, float4, double2>::type V;
+    if (VEC)
     {
-        const long long t = row0 + i / Dz;
-        const int c = (int)(i % Dz);
-        long long tt = t + c / p.D - p.left;
-        tt = tt < 0 ? 0 : (tt >= W ? W - 1 : tt);
-        z[i] = y[tt * p.D + c % p.D];
+        const int Dv = p.D / VW;
+        splice_rows<V, SUB>(p, Dv, utt.y_off / VW, SUB ? p.zrow[blockIdx.x] * K * Dv : utt.y_off / VW * K);
+    }
+    else { splice_rows<T, SUB>(p, p.D, utt.y_off, SUB ? p.zrow[blockIdx.x] * K * p.D : utt.y_off * K); }
+}
+
+template <bool SUB>
+void launch_splice(bool f64, const PostParams &p, dim3 g, hipStream_t s)
+{
+    if (f64)
+    {
+        if (p.vec16) { hipLaunchKernelGGL((splice_kernel<double, SUB, true>), g, dim3(NT), 0, s, p); }
+        else { hipLaunchKernelGGL((splice_kernel<double, SUB, false>), g, dim3(NT), 0, s, p); }
+    }
+    else
+    {
+        if (p.vec16) { hipLaunchKernelGGL((splice_kernel<float, SUB, true>), g, dim3(NT), 0, s, p); }
+        else { hipLaunchKernelGGL((splice_kernel<float, SUB, false>), g, dim3(NT), 0, s, p); }
     }
 }
 
 }  // namespace
+
+hipError_t launch_reduce_rows(const double *in, double *out, size_t n, int cols, hipStream_t s)
+{
+    if (n == 0) { return hipSuccess; }
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + POST_REDUCE_GROUP - 1) / POST_REDUCE_GROUP)), dim3(NT), 0, s, in, out, (unsigned long long)n, cols);
+    return hipGetLastError();
+}
 
 hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_frames, hipStream_t s)
 {
@@ -158,8 +268,16 @@ hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_fra
     {
         case POST_MOMENTS: if (f64) { hipLaunchKernelGGL(utt_moments_kernel<double>, g1, dim3(NT), 0, s, p); } else { hipLaunchKernelGGL(utt_moments_kernel<float>, g1, dim3(NT), 0, s, p); } break;
         case POST_AFFINE: if (f64) { hipLaunchKernelGGL(utt_affine_kernel<double>, g2, dim3(NT), lds, s, p); } else { hipLaunchKernelGGL(utt_affine_kernel<float>, g2, dim3(NT), lds, s, p); } break;
-        case POST_DELTAS: if (f64) { hipLaunchKernelGGL(add_deltas_kernel<double>, g2, dim3(NT), 0, s, p); } else { hipLaunchKernelGGL(add_deltas_kernel<float>, g2, dim3(NT), 0, s, p); } break;
-        case POST_SPLICE: if (f64) { hipLaunchKernelGGL(splice_kernel<double>, g2, dim3(NT), 0, s, p); } else { hipLaunchKernelGGL(splice_kernel<float>, g2, dim3(NT), 0, s, p); } break;
+        case POST_DELTAS:
+            if (p.order == 2 && p.window == 2)
+            {
+                if (f64) { hipLaunchKernelGGL((add_deltas_kernel<double, 2, 2>), g2, dim3(NT), 0, s, p); } else { hipLaunchKernelGGL((add_deltas_kernel<float, 2, 2>), g2, dim3(NT), 0, s, p); }
+            }
+            else if (f64) { hipLaunchKernelGGL((add_deltas_kernel<double, -1, -1>), g2, dim3(NT), 0, s, p); }
+            else { hipLaunchKernelGGL((add_deltas_kernel<float, -1, -1>), g2, dim3(NT), 0, s, p); }
+            break;
+        case POST_SPLICE: launch_splice<false>(f64, p, g2, s); break;
+        case POST_SPLICE_SUB: launch_splice<true>(f64, p, g2, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

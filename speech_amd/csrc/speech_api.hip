@@ -248,6 +248,10 @@ struct speech_batch {
     TileDesc *d_tiles;
     float *d_scratch;
     double *d_mom;               // post-processing: [nutt][2][D] moments, then [2][D] scale / offset (allocated on first use)
+    unsigned long long *d_zrow;  // splice + subsample: first output row of each utterance for (zrow_n, zrow_off); allocated on first use
+    std::vector<unsigned long long> zrow;
+    int zrow_n, zrow_off;
+    int yoff_pow2;               // largest of 1, 2, 4 that divides every utterance's output offset (-1: not computed yet)
     size_t total_samples, total_out, total_frames;
     hipEvent_t ev0, ev1;
 };
@@ -356,10 +360,26 @@ int post_begin(const char *fn, const speech_batch *b, PostParams *pp, uint32_t *
     return 0;
 }
 
+// splice: can the rows be copied in 16-byte units?
+int splice_vec16(speech_batch *b, const void *Y, const void *Z)
+{
+    if (b->yoff_pow2 < 0)
+    {
+        unsigned long long m = 0;
+        for (const UttDesc &u : b->utts) { m |= u.y_off; }
+        b->yoff_pow2 = (m & 1u) ? 1 : ((m & 2u) ? 2 : 4);
+    }
+    const size_t vw = b->plan->o.dtype == SPEECH_F64 ? 2u : 4u;
+    return (b->plan->sz.D % vw == 0u && (size_t)b->yoff_pow2 >= vw && ((uintptr_t)Y & 15u) == 0u && ((uintptr_t)Z & 15u) == 0u) ? 1 : 0;
+}
+
+// the batch's moment buffer: [nutt][2][D] per-utterance moments | [2][D] scale / offset of speech_batch_affine | the levels
+// of speech_batch_stats' reduction tree (ceil(nutt / 64) rows, then ceil of that / 64, ...)
+size_t mom_doubles(size_t nutt, size_t D) { return (nutt + 1u + nutt / (POST_REDUCE_GROUP - 1) + 8u) * 2u * D; }
+
 int post_moments(const char *fn, speech_batch *b, const void *Y, PostParams *pp, hipStream_t s)
 {
-    const size_t nd = (size_t)pp->nutt * 2 * pp->D + 2 * (size_t)pp->D;
-    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, nd * sizeof(double))); }
+    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, mom_doubles(pp->nutt, pp->D) * sizeof(double))); }
     pp->Yin = Y; pp->mom = b->d_mom;
     HIP_TRY(fn, launch_post(POST_MOMENTS, b->plan->o.dtype == SPEECH_F64, *pp, 0, s));
     return 0;
@@ -517,7 +537,7 @@ int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const s
     if (nutt > 0xFFFFFFFFull) { return fail(fn, "too many utterances"); }
     speech_batch *b = new (std::nothrow) speech_batch();
     if (!b) { return fail(fn, "out of host memory"); }
-    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_scratch = nullptr; b->d_mom = nullptr; b->ev0 = b->ev1 = nullptr;
+    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_scratch = nullptr; b->d_mom = nullptr; b->d_zrow = nullptr; b->zrow_n = b->zrow_off = -1; b->yoff_pow2 = -1; b->ev0 = b->ev1 = nullptr;
     b->total_samples = b->total_out = b->total_frames = 0;
     const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : GENERIC_TILE_FRAMES;
     const char *kfn = kind_name(p->o.kind, p->o.dtype);
@@ -567,6 +587,7 @@ void speech_batch_destroy(speech_batch *b)
     if (b->d_tiles) { (void)hipFree(b->d_tiles); }
     if (b->d_scratch) { (void)hipFree(b->d_scratch); }
     if (b->d_mom) { (void)hipFree(b->d_mom); }
+    if (b->d_zrow) { (void)hipFree(b->d_zrow); }
     if (b->ev0) { (void)hipEventDestroy(b->ev0); }
     if (b->ev1) { (void)hipEventDestroy(b->ev1); }
     delete b;
@@ -624,12 +645,23 @@ int speech_batch_stats(speech_batch *b, const void *Y, double *sum, double *sums
     if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
     hipStream_t s = (hipStream_t)stream;
     if (post_moments(fn, b, Y, &pp, s)) { return 1; }
-    std::vector<double> h((size_t)pp.nutt * 2 * D);
-    HIP_TRY(fn, hipMemcpyAsync(h.data(), b->d_mom, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(fn, hipStreamSynchronize(s));
-    for (uint32_t u = 0; u < pp.nutt; ++u)                                   // utterance order: the same sums on every run
+    // a tree of fixed shape over the utterances (groups of 64 in order, on the device; the last <= 64 rows on the host):
+    // the same sums on every run, and only a few KB cross PCIe
+    size_t n = pp.nutt;
+    const double *src = b->d_mom;
+    double *dst = b->d_mom + ((size_t)pp.nutt + 1u) * 2u * (size_t)D;
+    while (n > (size_t)POST_REDUCE_GROUP)
     {
-        for (int d = 0; d < D; ++d) { sum[d] += h[(size_t)u * 2 * D + d]; sumsq[d] += h[(size_t)u * 2 * D + D + d]; }
+        HIP_TRY(fn, launch_reduce_rows(src, dst, n, 2 * D, s));
+        n = (n + POST_REDUCE_GROUP - 1) / POST_REDUCE_GROUP;
+        src = dst; dst += n * 2u * (size_t)D;
+    }
+    std::vector<double> h(n * 2u * (size_t)D);
+    HIP_TRY(fn, hipMemcpyAsync(h.data(), src, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(fn, hipStreamSynchronize(s));
+    for (size_t u = 0; u < n; ++u)
+    {
+        for (int d = 0; d < D; ++d) { sum[d] += h[u * 2 * D + d]; sumsq[d] += h[u * 2 * D + D + d]; }
     }
     return 0;
 }
@@ -661,8 +693,8 @@ int speech_batch_affine(speech_batch *b, void *Y, const double *scale, const dou
     DeviceGuard g(b->plan->device);
     if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
     hipStream_t s = (hipStream_t)stream;
-    const size_t D = (size_t)pp.D, nd = (size_t)pp.nutt * 2 * D + 2 * D;
-    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, nd * sizeof(double))); }
+    const size_t D = (size_t)pp.D;
+    if (!b->d_mom) { HIP_TRY(fn, hipMalloc((void **)&b->d_mom, mom_doubles(pp.nutt, D) * sizeof(double))); }
     double *d_aff = b->d_mom + (size_t)pp.nutt * 2 * D;
     std::vector<double> h(2 * D);
     for (size_t d = 0; d < D; ++d) { h[d] = scale[d]; h[D + d] = offset[d]; }
@@ -714,8 +746,57 @@ int speech_batch_splice(speech_batch *b, const void *Y, void *Z, int left, int r
     if (Y == Z) { return fail(fn, "splice cannot run in place"); }
     DeviceGuard g(b->plan->device);
     if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
-    pp.Yin = Y; pp.Y = Z; pp.left = left; pp.right = right;
+    pp.Yin = Y; pp.Y = Z; pp.left = left; pp.right = right; pp.vec16 = splice_vec16(b, Y, Z);
     HIP_TRY(fn, launch_post(POST_SPLICE, b->plan->o.dtype == SPEECH_F64, pp, mw, (hipStream_t)stream));
+    return 0;
+}
+
+int speech_batch_subsample_rows(const speech_batch *b, int n, int offset, size_t *rows, size_t *total_rows)
+{
+    const char *fn = "speech_batch_subsample_rows";
+    if (!b || !b->plan) { return fail(fn, "null batch"); }
+    if (n < 1 || offset < 0 || offset >= n) { return fail(fn, "need n >= 1 and 0 <= offset < n"); }
+    size_t tot = 0;
+    for (size_t u = 0; u < b->utts.size(); ++u)
+    {
+        const size_t W = (size_t)b->utts[u].W, r = W > (size_t)offset ? (W - (size_t)offset + (size_t)n - 1u) / (size_t)n : 0u;
+        if (rows) { rows[u] = r; }
+        tot += r;
+    }
+    if (total_rows) { *total_rows = tot; }
+    return 0;
+}
+
+int speech_batch_splice_subsample(speech_batch *b, const void *Y, void *Z, int left, int right, int n, int offset, void *stream)
+{
+    const char *fn = "speech_batch_splice_subsample";
+    PostParams pp; uint32_t mw;
+    if (post_begin(fn, b, &pp, &mw)) { return 1; }
+    if (left < 0 || right < 0 || left > 64 || right > 64) { return fail(fn, "left and right context must be in [0 64]"); }
+    if (n < 1 || offset < 0 || offset >= n) { return fail(fn, "need n >= 1 and 0 <= offset < n"); }
+    if (pp.nutt == 0 || b->total_frames == 0) { return 0; }
+    if (!Y || !Z) { return fail(fn, "null device pointer"); }
+    if (Y == Z) { return fail(fn, "splice cannot run in place"); }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    hipStream_t s = (hipStream_t)stream;
+    if (!b->d_zrow) { HIP_TRY(fn, hipMalloc((void **)&b->d_zrow, b->utts.size() * sizeof(unsigned long long))); }
+    if (b->zrow_n != n || b->zrow_off != offset)
+    {
+        HIP_TRY(fn, hipStreamSynchronize(s));                                // an earlier call on this stream may still read the table
+        b->zrow.resize(b->utts.size());
+        unsigned long long acc = 0;
+        for (size_t u = 0; u < b->utts.size(); ++u)
+        {
+            b->zrow[u] = acc;
+            const unsigned long long W = b->utts[u].W;
+            acc += W > (unsigned long long)offset ? (W - (unsigned long long)offset + (unsigned long long)n - 1u) / (unsigned long long)n : 0u;
+        }
+        HIP_TRY(fn, hipMemcpy(b->d_zrow, b->zrow.data(), b->zrow.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        b->zrow_n = n; b->zrow_off = offset;
+    }
+    pp.Yin = Y; pp.Y = Z; pp.left = left; pp.right = right; pp.sub_n = n; pp.sub_off = offset; pp.zrow = b->d_zrow; pp.vec16 = splice_vec16(b, Y, Z);
+    HIP_TRY(fn, launch_post(POST_SPLICE_SUB, b->plan->o.dtype == SPEECH_F64, pp, (mw + (uint32_t)n - 1u) / (uint32_t)n, s));
     return 0;
 }
 
@@ -784,10 +865,11 @@ int stage_reserve(const char *fn, StageBuffers &sb, int dev, size_t bytesX, size
     return 0;
 }
 
+// X16 non-null: the audio is 16-bit PCM on the host (speech_extract_pcm16), X unused
 template <typename T>
-int legacy_call(speech_opts &o, T *Y, const T *X, size_t N)
+int legacy_call(speech_opts &o, T *Y, const T *X, size_t N, const short *X16 = nullptr)
 {
-    const char *fn = kind_name(o.kind, o.dtype);
+    const char *fn = X16 ? "speech_extract_pcm16" : kind_name(o.kind, o.dtype);
     if (N < 1u) { return fail(fn, "N (nsamps in signal) must be positive"); }                 // c/kaldi_mfcc.c:54
     Sizes sz;
     if (validate<T>(o, &sz)) { return 1; }
@@ -796,21 +878,22 @@ int legacy_call(speech_opts &o, T *Y, const T *X, size_t N)
     const size_t W = o.snip_edges ? 1u + (N - sz.L) / sz.stp : (N + sz.stp / 2u) / sz.stp;     // c/kaldi_mfcc.c:77
     if (W == 0u) { return 0; }                                                                 // c/kaldi_mfcc.c:78 (before the window name is looked at)
     if (!window_known(o.win_type)) { return fail(fn, "window type must be rectangular, blackman, hamming, hann or povey (lower-cased)"); }
-    if (!X || !Y) { return fail(fn, "null pointer"); }
+    if ((!X && !X16) || !Y) { return fail(fn, "null pointer"); }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { return fail(fn, "no HIP device available (this library has no CPU fallback)"); }
     speech_plan *p = cached_plan(o, dev);
     if (!p) { return 1; }
     static thread_local StageBuffers sb;
     const size_t nout = W * sz.D;
-    if (stage_reserve(fn, sb, dev, N * sizeof(T), nout * sizeof(T))) { return 1; }
+    const size_t xbytes = X16 ? N * sizeof(short) : N * sizeof(T);
+    if (stage_reserve(fn, sb, dev, xbytes, nout * sizeof(T))) { return 1; }
     speech_batch *b = nullptr;
     int rc = 1;
     do
     {
         if (speech_batch_create(&b, p, 1u, &N, nullptr, nullptr)) { break; }
-        if (hipMemcpy(sb.dX, X, N * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { fail(fn, "problem copying X to the device"); break; }
-        if (speech_batch_run(b, sb.dX, sb.dY, nullptr)) { break; }
+        if (hipMemcpy(sb.dX, X16 ? (const void *)X16 : (const void *)X, xbytes, hipMemcpyHostToDevice) != hipSuccess) { fail(fn, "problem copying X to the device"); break; }
+        if (X16 ? speech_batch_run_pcm16(b, (const short *)sb.dX, sb.dY, nullptr, nullptr) : speech_batch_run(b, sb.dX, sb.dY, nullptr)) { break; }
         if (hipMemcpy(Y, sb.dY, nout * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) { fail(fn, "kernel execution or copy of Y failed"); break; }
         rc = 0;
     } while (0);
@@ -829,6 +912,16 @@ void front(speech_opts &o, int kind, T sr, T fl, T fs, int snip, T dither, int d
 }
 
 }  // namespace
+
+extern "C" int speech_extract_pcm16(const speech_opts *opts, const short *X16, size_t N, void *Y)
+{
+    if (!opts) { return fail("speech_extract_pcm16", "null opts"); }
+    if (!X16 && N > 0u) { return fail("speech_extract_pcm16", "null pointer"); }
+    speech_opts o = *opts;
+    o.win_type[sizeof(o.win_type) - 1] = '\0';
+    if (o.dtype == SPEECH_F64) { return legacy_call<double>(o, (double *)Y, nullptr, N, X16); }
+    return legacy_call<float>(o, (float *)Y, nullptr, N, X16);
+}
 
 namespace codee {
 extern "C" {

@@ -119,7 +119,7 @@ struct FrameParams {
 
 // corpus post-processing (post_kernels.hip)
 constexpr int POST_MAX_ORDER = 3, POST_MAX_WINDOW = 5, POST_MAX_TAPS = 2 * POST_MAX_ORDER * POST_MAX_WINDOW + 1;
-enum { POST_MOMENTS = 0, POST_AFFINE = 1, POST_DELTAS = 2, POST_SPLICE = 3 };
+enum { POST_MOMENTS = 0, POST_AFFINE = 1, POST_DELTAS = 2, POST_SPLICE = 3, POST_SPLICE_SUB = 4 };
 struct PostParams {
     void *Y;                     // in place (affine) or output (deltas, splice)
     const void *Yin;             // input (moments, deltas, splice)
@@ -130,9 +130,15 @@ struct PostParams {
     const double *scale, *offset;    // affine mode 0: [D] each (device)
     int mode, norm_vars;
     int order, window, left, right;
+    int vec16;                       // splice: D, every utterance's offset and both arrays allow 16-byte units
+    int sub_n, sub_off;              // splice + subsample: output row j of an utterance is spliced frame sub_off + j sub_n
+    const unsigned long long *zrow;  // [nutt] first output row of each utterance in the dense packing
     double dscale[POST_MAX_ORDER + 1][POST_MAX_TAPS];    // delta filters, centred: order k has 2 k window + 1 taps
 };
 hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_frames, hipStream_t s);
+constexpr int POST_REDUCE_GROUP = 64;
+// out[g][c] = sum of in[64 g .. 64 g + 63][c] in row order; out holds ceil(n / 64) rows
+hipError_t launch_reduce_rows(const double *in, double *out, size_t n, int cols, hipStream_t s);
 
 // launchers (defined in the kernel translation units)
 hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s);

@@ -162,3 +162,64 @@ def test_ark_and_scp_output(tmp_path):
     assert r.returncode == 0
     d = read_ark(tmp_path / "d.ark")["d"][1]
     assert d.dtype == np.float64 and np.array_equal(d, api.kaldi_spectrogram(xs["utt-a"].astype(np.float64)))
+
+
+def _wav_bytes(x, rate=16000, channels=1, extra_chunk=False, data_size=None, bits=16, tag=1):
+    """RIFF/WAVE writer for the tests (stdlib `wave` cannot write LIST chunks or open-ended data sizes)"""
+    import struct
+    x = np.asarray(x, dtype=np.int16)
+    data = x.tobytes()
+    fmt = struct.pack("<HHIIHH", tag, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if extra_chunk:
+        body += b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\0"      # odd size: padded to even
+    body += b"data" + struct.pack("<I", len(data) if data_size is None else data_size) + data
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_wav_input_validates_on_cpu(tmp_path):
+    """errors that are found before anything touches the GPU"""
+    x = (signals.utterance(4000, 3)).astype(np.int16)
+    cases = [(_wav_bytes(x, bits=8), (), "only 16-bit PCM is supported"), (_wav_bytes(x, tag=3), (), "only 16-bit PCM is supported"),
+             (_wav_bytes(x, rate=8000), ("-r", "16000"), "does not match the .wav header (8000 Hz)"),
+             (_wav_bytes(x), ("--channel=1",), "channel not in file"), (b"RIFF\0\0\0\0WAVX", (), "not a RIFF/WAVE file"),
+             (_wav_bytes(x)[:30], (), "bad fmt chunk"), (_wav_bytes(x)[:36], (), "no data chunk"), (_wav_bytes(x[:0]), (), "input (X) found to be empty")]
+    for i, (blob, args, msg) in enumerate(cases):
+        f = tmp_path / ("bad%d.wav" % i)
+        f.write_bytes(blob)
+        r = run("kaldi_mfcc", "-d0", *args, str(f), "-o", str(tmp_path / "y.npy"))
+        assert r.returncode == 1 and msg in r.stderr.decode(), (i, r.stderr)
+    r = run("kaldi_mfcc", "-h")
+    assert "--channel=<n>" in r.stdout.decode()
+
+
+@pytest.mark.gpu
+def test_wav_input_matches_float_input(tmp_path):
+    """a 16-bit PCM .wav goes to the device as int16 and gives the features of the same samples as floats, bit for bit"""
+    import io
+    from speech_amd import api
+    x = signals.utterance(12000, 77).astype(np.int16)
+    xf = x.astype(np.float32)
+    w = tmp_path / "x.wav"
+    w.write_bytes(_wav_bytes(x, extra_chunk=True))
+    r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", str(w), "-o", str(tmp_path / "y.npy"))
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.load(tmp_path / "y.npy"), api.kaldi_mfcc(xf))
+    # sample rate from the header (8 kHz -> 200-sample frames); stdin; open-ended data chunk as streamed files have it
+    r = run("kaldi_fbank", "-e", "-z", "-y", "-d0", "-g", "-b", "40", "-", stdin=_wav_bytes(x, rate=8000, data_size=0xFFFFFFFF))
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.load(io.BytesIO(r.stdout)), api.kaldi_fbank(xf, sr=8000.0, hif=4000.0, B=40))
+    # stereo: the chosen channel; a data size beyond the file's end gives what the file holds
+    st = np.stack([x, x[::-1]], axis=1)
+    w2 = tmp_path / "st.wav"
+    w2.write_bytes(_wav_bytes(st, channels=2, data_size=4 * x.size + 400))
+    for ch, want in ((0, xf), (1, xf[::-1].copy())):
+        r = run("kaldi_spectrogram", "-e", "-z", "-d0", "--channel=%d" % ch, str(w2), "-o", str(tmp_path / "s.npy"))
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(np.load(tmp_path / "s.npy"), api.kaldi_spectrogram(want, raw_energy=0))
+    # ark output from a .wav, the compute-mfcc-feats use
+    r = run("kaldi_plp", "-e", "-z", "-y", "-d0", "--ark=utt1", str(w), "-o", str(tmp_path / "p.ark"))
+    assert r.returncode == 0, r.stderr
+    from speech_amd import ark
+    (key, _, m), = list(ark.read_ark(str(tmp_path / "p.ark")))
+    assert key == "utt1" and np.array_equal(m, api.kaldi_plp(xf))

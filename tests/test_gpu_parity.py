@@ -393,6 +393,24 @@ def test_which_plans_run_on_the_tuned_kernels():
     assert not api.Plan("mfcc", dtype="f64").tuned
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_extract_pcm16_equals_the_drop_in_call(dtype):
+    """speech_extract_pcm16 (host int16 in, host features out) = the drop-in call on the same samples as floats; same errors"""
+    x = signals.utterance(20000, 1300)
+    x16 = x.astype(np.int16)
+    t = np.float32 if dtype == "f32" else np.float64
+    assert np.array_equal(api.extract_pcm16("mfcc", x16, dtype), api.kaldi_mfcc(x.astype(t)))
+    assert np.array_equal(api.extract_pcm16("fbank", x16, dtype, B=40, snip_edges=0, use_energy=1), api.kaldi_fbank(x.astype(t), B=40, snip_edges=0, use_energy=1))
+    assert np.array_equal(api.extract_pcm16("spectrogram", x16[:8000], dtype, sr=8000.0), api.kaldi_spectrogram(x[:8000].astype(t), sr=8000.0))
+    assert np.array_equal(api.extract_pcm16("plp", x16, dtype, mn0=1), api.kaldi_plp(x.astype(t), mn0=1))
+    assert api.extract_pcm16("mfcc", x16[:100], dtype, snip_edges=0).shape == (1, 13)
+    for bad in (dict(snip_edges=1), dict(win_type="kaiser", snip_edges=0), dict(C=30, snip_edges=0)):
+        with pytest.raises(api.SpeechError):
+            api.extract_pcm16("mfcc", x16[:100], dtype, **bad)
+    with pytest.raises(TypeError):
+        api.extract_pcm16("mfcc", x, dtype)
+
+
 @pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(snip=0)), ("plp", {}),
                                     ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("fbank", dict(B=40, snip=0, force_generic=1))])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])

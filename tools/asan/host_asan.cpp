@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <hip/hip_runtime.h>
 #include "../../include/codee_speech.h"
 #include "../../include/speech_hip.h"
 
@@ -69,6 +70,47 @@ int main()
             EXPECT(speech_batch_stats(b, nullptr, sum.data(), sq.data(), &frames, nullptr) == 1);      // null device pointer
             speech_batch_destroy(b);
         }
+        // a batch of 200 utterances on the device: run, statistics through the two-level tree, CMVN, deltas, splice + subsample
+        std::vector<size_t> many(200);
+        size_t tot = 0;
+        for (size_t i = 0; i < many.size(); ++i) { many[i] = 160u * (1u + (7u * i) % 5u); tot += many[i]; }
+        EXPECT(speech_batch_create(&b, plan, many.size(), many.data(), nullptr, nullptr) == 0);
+        if (b)
+        {
+            size_t ns = 0, no = 0, nf = 0, zr = 0;
+            EXPECT(speech_batch_totals(b, &ns, &no, &nf) == 0 && ns == tot);
+            std::vector<size_t> rows(many.size());
+            EXPECT(speech_batch_subsample_rows(b, 3, 1, rows.data(), &zr) == 0);
+            EXPECT(speech_batch_subsample_rows(b, 3, 3, nullptr, &zr) == 1);
+            float *dX = nullptr, *dY = nullptr, *dZ = nullptr;
+            EXPECT(hipMalloc((void **)&dX, ns * 4) == hipSuccess && hipMalloc((void **)&dY, no * 4) == hipSuccess && hipMalloc((void **)&dZ, no * 3 * 4) == hipSuccess);
+            if (dX && dY && dZ)
+            {
+                std::vector<float> xs(ns);
+                for (size_t i = 0; i < ns; ++i) { xs[i] = x[i % x.size()]; }
+                EXPECT(hipMemcpy(dX, xs.data(), ns * 4, hipMemcpyHostToDevice) == hipSuccess);
+                EXPECT(speech_batch_run(b, dX, dY, nullptr) == 0);
+                std::vector<double> sum(13), sq(13); unsigned long long frames = 0;
+                EXPECT(speech_batch_stats(b, dY, sum.data(), sq.data(), &frames, nullptr) == 0 && frames == nf);
+                EXPECT(speech_batch_cmvn(b, dY, 1, nullptr) == 0);
+                EXPECT(speech_batch_affine(b, dY, sum.data(), sq.data(), nullptr) == 0);
+                EXPECT(speech_batch_add_deltas(b, dY, dZ, 2, 2, nullptr) == 0);
+                EXPECT(speech_batch_splice(b, dY, dZ, 1, 1, nullptr) == 0);
+                EXPECT(speech_batch_splice_subsample(b, dY, dZ, 3, 3, 3, 1, nullptr) == 0);
+                EXPECT(speech_batch_splice_subsample(b, dY, dZ, 0, 0, 2, 0, nullptr) == 0);       // the offset table is re-made
+                EXPECT(speech_batch_splice_subsample(b, dY, dZ, 0, 0, 2, 2, nullptr) == 1);
+                EXPECT(hipDeviceSynchronize() == hipSuccess);
+            }
+            (void)hipFree(dX); (void)hipFree(dY); (void)hipFree(dZ);
+            speech_batch_destroy(b);
+        }
+        // 16-bit PCM from host memory
+        std::vector<short> x16(20000);
+        for (size_t i = 0; i < x16.size(); ++i) { x16[i] = (short)x[i]; }
+        std::vector<float> y16(200 * 13, 0.0f);
+        EXPECT(speech_extract_pcm16(&o, x16.data(), x16.size(), y16.data()) == 0);
+        EXPECT(speech_extract_pcm16(&o, nullptr, x16.size(), y16.data()) == 1);
+        EXPECT(speech_extract_pcm16(nullptr, x16.data(), x16.size(), y16.data()) == 1);
         speech_plan_destroy(plan);
     }
     printf("host asan run: %d failure(s)\n", fails);
