@@ -174,41 +174,51 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
             rawe = block_sum<T, NTH>(s, red);
             if (rawe < eps) { rawe = eps; }
         }
-        // FFT (replaces the FFTW R2HC call, c/kaldi_mfcc.c:304): radix-2 DIT on the zero-padded frame
-        for (int l = tid; l < nfft; l += NTH) { re[__brev((unsigned)l) >> (32 - p.log2n)] = im[l]; }
-        __syncthreads();
-        for (int l = tid; l < nfft; l += NTH) { im[l] = (T)0; }
+        // FFT (replaces the FFTW R2HC call, c/kaldi_mfcc.c:304) of the zero-padded real frame as a complex FFT of half the
+        // size: z[m] = x[2m] + i x[2m+1], radix-2 DIT on n2 = nfft / 2 points in (zr, zi) = the two halves of `re`
+        const int n2 = nfft >> 1, lg2 = p.log2n - 1;
+        T *zr = re, *zi = re + n2;
+        T *pw = im;                                        // the power spectrum replaces the windowed frame
+        if (nfft == 1)
+        {
+            if (tid == 0) { const T v = im[0]; pw[0] = v * v; }
+            __syncthreads();
+        }
+        else
+        {
+        for (int m = tid; m < n2; m += NTH)
+        {
+            const int r = (lg2 > 0) ? (int)(__brev((unsigned)m) >> (32 - lg2)) : 0;
+            zr[r] = im[2 * m]; zi[r] = im[2 * m + 1];
+        }
         __syncthreads();
         // two radix-2 stages per pass over LDS: the four points a, b = a + half, c = a + 2 half, d = a + 3 half go through
-        // stage `half` (pairs a-b and c-d) and stage `2 half` (pairs a-c and b-d) in registers, with the same operations in
-        // the same order as two separate passes -- the results are bit-identical, for half the LDS traffic and barriers
+        // stage `half` (pairs a-b and c-d) and stage `2 half` (pairs a-c and b-d) in registers: half the LDS traffic and
+        // barriers of one stage per pass.  The twiddle of span `half` is exp(-2 pi i k / (2 half)) = tw[k nfft / (2 half)].
         int half = 1;
-        if (p.log2n & 1)
+        if (lg2 & 1)
         {
-            for (int i = tid; i < nfft / 2; i += NTH)                      // lone first stage: twiddle 1
+            for (int i = tid; i < n2 / 2; i += NTH)                        // lone first stage: twiddle 1
             {
                 const int a = i << 1, b = a + 1;
-                const T c = twr[0], s = twi[0];
-                const T tr = re[b] * c - im[b] * s;
-                const T ti = re[b] * s + im[b] * c;
-                const T ar = re[a], ai = im[a];
-                re[b] = ar - tr; im[b] = ai - ti;
-                re[a] = ar + tr; im[a] = ai + ti;
+                const T ar = zr[a], ai = zi[a], br = zr[b], bi = zi[b];
+                zr[b] = ar - br; zi[b] = ai - bi;
+                zr[a] = ar + br; zi[a] = ai + bi;
             }
             __syncthreads();
             half = 2;
         }
-        for (; half < nfft; half <<= 2)
+        for (; half < n2; half <<= 2)
         {
             const int t1 = nfft / (2 * half), t2 = nfft / (4 * half);
-            for (int i = tid; i < nfft / 4; i += NTH)
+            for (int i = tid; i < n2 / 4; i += NTH)
             {
                 const int k = i & (half - 1);
                 const int a = ((i - k) << 2) + k, b = a + half, c = b + half, d = c + half;
                 const T c1 = twr[k * t1], s1 = twi[k * t1];
                 const T c2 = twr[k * t2], s2 = twi[k * t2];
                 const T c3 = twr[(k + half) * t2], s3 = twi[(k + half) * t2];
-                T ar = re[a], ai = im[a], br = re[b], bi = im[b], cr = re[c], ci = im[c], dr = re[d], di = im[d];
+                T ar = zr[a], ai = zi[a], br = zr[b], bi = zi[b], cr = zr[c], ci = zi[c], dr = zr[d], di = zi[d];
                 // stage `half`
                 T tr = br * c1 - bi * s1, ti = br * s1 + bi * c1;
                 br = ar - tr; bi = ai - ti; ar = ar + tr; ai = ai + ti;
@@ -219,25 +229,37 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
                 cr = ar - tr; ci = ai - ti; ar = ar + tr; ai = ai + ti;
                 tr = dr * c3 - di * s3; ti = dr * s3 + di * c3;
                 dr = br - tr; di = bi - ti; br = br + tr; bi = bi + ti;
-                re[a] = ar; im[a] = ai; re[b] = br; im[b] = bi; re[c] = cr; im[c] = ci; re[d] = dr; im[d] = di;
+                zr[a] = ar; zi[a] = ai; zr[b] = br; zi[b] = bi; zr[c] = cr; zi[c] = ci; zr[d] = dr; zi[d] = di;
             }
             __syncthreads();
         }
-        // power, c/kaldi_mfcc.c:307-310 (im[0] = im[nfft/2] = 0 for a real input up to rounding; the reference never adds them)
+        // untangle + power, c/kaldi_mfcc.c:307-310: with A = Z[k] + conj Z[n2-k], B = Z[k] - conj Z[n2-k] and
+        // w = exp(-2 pi i k / nfft), X[k] = (A - i w B) / 2.  X[0] = Zr[0] + Zi[0] and X[nfft/2] = Zr[0] - Zi[0] are real
+        // (the reference never adds their imaginary parts).
         for (int k = tid; k < F; k += NTH)
         {
-            T pw = re[k] * re[k];
-            if (k > 0 && k < F - 1) { pw += im[k] * im[k]; }
-            re[k] = pw;
+            T v;
+            if (k == 0) { const T x0 = zr[0] + zi[0]; v = x0 * x0; }
+            else if (k == n2) { const T xn = zr[0] - zi[0]; v = xn * xn; }
+            else
+            {
+                const T pr = zr[k], pi = zi[k], qr = zr[n2 - k], qi = zi[n2 - k];
+                const T Ar = pr + qr, Ai = pi - qi, Br = pr - qr, Bi = pi + qi;
+                const T c = twr[k], s = twi[k];
+                const T xr = Ar + (c * Bi + s * Br), xi = Ai - (c * Br - s * Bi);
+                v = (T)0.25 * (xr * xr + xi * xi);
+            }
+            pw[k] = v;
         }
         __syncthreads();
+        }
 
         if (p.kind == SPEECH_SPECTROGRAM)
         {
             // c/kaldi_spectrogram.c:236-251
             for (int k = tid; k < F; k += NTH)
             {
-                const T v = (k == 0) ? rawe : ((k == F - 1) ? re[F - 2] : re[k]);
+                const T v = (k == 0) ? rawe : ((k == F - 1) ? pw[F - 2] : pw[k]);
                 y[k] = floor_log(v);
             }
             continue;
@@ -251,7 +273,7 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
             T sm = (T)0;
             for (int f = 0; f < num; ++f)
             {
-                T pv = re[beg + f];
+                T pv = pw[beg + f];
                 if (p.amp) { pv = M<T>::sqrt(pv); }
                 sm += pv * wgt[f];
             }
