@@ -73,6 +73,9 @@ void speech_batch_destroy(speech_batch *batch);
 /* totals: samples read, features written (elements), frames; and the element offsets actually used. */
 int speech_batch_totals(const speech_batch *batch, size_t *total_samples, size_t *total_out, size_t *total_frames);
 int speech_batch_offsets(const speech_batch *batch, size_t *x_off, size_t *y_off, size_t *n_frames);
+/* Dither only: utterance u of the batch draws its noise as utterance number ids[u] (default, or ids == NULL: u), so that a
+   corpus cut into several batches, or sharded over ranks, gets the noise it would get as one batch.  Waits for the device. */
+int speech_batch_set_ids(speech_batch *batch, const unsigned int *ids);
 
 /* Enqueue the whole batch on `stream` (hipStream_t as void*, NULL = default stream).  X and Y are device
    pointers of the plan's dtype.  Asynchronous: returns after the launches are queued. */
@@ -92,6 +95,18 @@ int speech_batch_run_pcm16(speech_batch *batch, const short *X16_dev, void *Y_de
    (validation, error style, plan cache, staging buffers), with half the bytes over PCIe.  Y must hold W x D elements
    (speech_plan_num_frames / the reference's W formula, c/kaldi_mfcc.c:77). */
 int speech_extract_pcm16(const speech_opts *opts, const short *X16_host, size_t N, void *Y_host);
+
+/* A ragged batch from host memory to host memory: what the reference's callers hold (src/kaldi_mfcc.cpp:286-308), for many
+   utterances at once.  X[u] points at utterance u's n_samples[u] samples (the plan's dtype, or 16-bit PCM when pcm16 != 0),
+   Y[u] at room for its W_u x D features (the plan's dtype).  The utterances are cut into chunks of about chunk_bytes of
+   input (0 = 64 MiB; a chunk holds at least one utterance); each chunk is packed into pinned memory, copied, run as one
+   batch and copied back on one of two streams, so that copies and packing overlap the kernels.  The features equal
+   speech_batch_run on the whole list bit for bit (dithered plans included).  Synchronous: Y is complete on return.  The
+   staging buffers (device and pinned, about 2 x (chunk input + chunk output)) belong to the calling thread and are kept
+   for later calls; speech_host_release frees them. */
+int speech_plan_run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t *n_samples, void *const *Y,
+                         int pcm16, size_t chunk_bytes);
+void speech_host_release(void);
 
 /* Widening: corpus post-processing on a batch's packed features Y_dev (frame-major W x D per utterance,
    the layout speech_batch_run writes).  The reference's only post-pass is mn0, the per-utterance mean subtraction

@@ -145,6 +145,27 @@ class Plan:
             return None
         return W.value
 
+    def run_host(self, xs, chunk_bytes=0, out=None):
+        """features of a list of utterances held in host memory (numpy arrays of the plan's dtype, or all int16 = 16-bit PCM),
+        as a list of W_u x D numpy arrays: speech_plan_run_host, chunked and overlapped host -> device -> host"""
+        n = len(xs)
+        pcm16 = n > 0 and all(np.asarray(x).dtype == np.int16 for x in xs)
+        dt = np.int16 if pcm16 else self.np_dtype
+        xs = [np.ascontiguousarray(x, dtype=dt).reshape(-1) for x in xs]
+        ys = out if out is not None else []
+        if out is None:
+            for x in xs:
+                W = self.num_frames(x.size)
+                if W is None:
+                    raise SpeechError("an utterance of %d samples is not valid for this plan" % x.size)
+                ys.append(np.zeros((W, self.D), dtype=self.np_dtype))
+        Xp = (C.c_void_p * max(1, n))(*[x.ctypes.data for x in xs])
+        Yp = (C.c_void_p * max(1, n))(*[y.ctypes.data if y.size else xs[0].ctypes.data for y in ys])
+        Np = (C.c_size_t * max(1, n))(*[x.size for x in xs])
+        if self._lib.speech_plan_run_host(self._h, n, Xp, Np, Yp, int(pcm16), int(chunk_bytes)) != 0:
+            raise SpeechError(_lib.last_error())
+        return ys
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.speech_plan_destroy(self._h)
@@ -245,6 +266,16 @@ class Batch:
         """Z (total_out * (left + right + 1) elements) = frames spliced with their neighbours, Kaldi splice-feats"""
         self._check(self._lib.speech_batch_splice(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(left), int(right),
                                                   C.c_void_p(stream) if stream else None))
+
+    def set_ids(self, ids=None):
+        """dither: utterance u draws its noise as utterance number ids[u] (None: its index in the batch)"""
+        if ids is None:
+            self._check(self._lib.speech_batch_set_ids(self._h, None))
+            return
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        if a.shape != (self.nutt,):
+            raise ValueError("ids must have one entry per utterance")
+        self._check(self._lib.speech_batch_set_ids(self._h, a.ctypes.data_as(C.POINTER(C.c_uint))))
 
     def subsample_rows(self, n, offset=0):
         """(rows per utterance, total rows) of splice_subsample's output for --n=n --offset=offset"""

@@ -98,14 +98,14 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (nfr > 0 && PAIR)
     {
         // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its row is never stored)
-        const unsigned long long ku = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) : 0ull;
+        const unsigned long long ku = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.uid << 32)) : 0ull;
         const unsigned long long wa = (unsigned long long)((long long)tile.frame0 + fq + 2 * f);
         const unsigned long long ka = DITHER ? dither_frame_key(ku, wa) : 0ull, kb = DITHER ? dither_frame_key(ku, wa + 1) : 0ull;
         frame_power_pair<NZ, true, DITHER>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab, s_tr, lane, p, ka, kb, pa, pb, rawe2);
     }
     else if (nfr > 0)
     {
-        const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.utt << 32)),
+        const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)),
                                                                   (unsigned long long)((long long)tile.frame0 + fq + f)) : 0ull;
         frame_power<NZ, true, DITHER>(s_aud + f * p.stp, s_tab, s_tr, lane, p, dkey, pa, pb, rawe);
     }

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     constexpr int FW = PAIR ? 2 * QF : QF;                                  // frames per wave
     constexpr int SUBF = (NT / 64) * FW;                                    // frames per sub-tile
     const int nsub = ((int)tile.nframes + SUBF - 1) / SUBF;
-    const unsigned long long dkey_utt = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.utt << 32)) : 0ull;
+    const unsigned long long dkey_utt = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.uid << 32)) : 0ull;
     long long s0; int need;
     int nfr = quad_geom(p, tile, wv * FW, s0, need, FW);
     if (nfr > 0) { load_span(s_aud, xu, xu16, s0, need, N, lane); }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
         if (p.do_dither)
         {
             // Gaussian pairs by Box-Muller as c/kaldi_mfcc.c:243-262, from a counter-based hash (speech_internal.hpp)
-            const unsigned long long key = dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.utt << 32)), (unsigned long long)w);
+            const unsigned long long key = dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)), (unsigned long long)w);
             for (int i = tid; 2 * i < L; i += NTH)
             {
                 T g0, g1;

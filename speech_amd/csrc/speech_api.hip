@@ -37,7 +37,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &p, float *
 
 static thread_local std::string g_err;
 
-static int fail(const char *fn, const char *fmt, ...)
+int fail(const char *fn, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -531,6 +531,14 @@ int speech_plan_num_frames(const speech_plan *p, size_t N, size_t *W)
 
 int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off)
 {
+    return speech::batch_create(out, p, nutt, n_samples, x_off, y_off, 0u);
+}
+
+}  // extern "C"
+
+// uid_base: the dither number of the batch's first utterance (utterance u draws its noise as utterance uid_base + u)
+int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base)
+{
     const char *fn = "speech_batch_create";
     if (!out || !p || (nutt && !n_samples)) { return fail(fn, "null argument"); }
     *out = nullptr;
@@ -557,7 +565,7 @@ int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const s
         b->total_samples += N; b->total_out += W * p->sz.D; b->total_frames += W;
         for (size_t f0 = 0; f0 < W; f0 += (size_t)tile)
         {
-            TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.pad = 0;
+            TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.uid = uid_base + (uint32_t)u;
             b->tiles.push_back(t);
         }
     }
@@ -578,6 +586,15 @@ int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const s
     *out = b;
     return 0;
 }
+
+void speech::plan_info(const speech_plan *p, int *device, int *dtype, size_t *D)
+{
+    if (device) { *device = p->device; }
+    if (dtype) { *dtype = p->o.dtype; }
+    if (D) { *D = p->sz.D; }
+}
+
+extern "C" {
 
 void speech_batch_destroy(speech_batch *b)
 {
@@ -611,6 +628,19 @@ int speech_batch_offsets(const speech_batch *b, size_t *x_off, size_t *y_off, si
         if (y_off) { y_off[u] = (size_t)b->utts[u].y_off; }
         if (n_frames) { n_frames[u] = (size_t)b->utts[u].W; }
     }
+    return 0;
+}
+
+int speech_batch_set_ids(speech_batch *b, const unsigned int *ids)
+{
+    const char *fn = "speech_batch_set_ids";
+    if (!b || !b->plan) { return fail(fn, "null batch"); }
+    for (TileDesc &t : b->tiles) { t.uid = ids ? (uint32_t)ids[t.utt] : t.utt; }
+    if (b->tiles.empty()) { return 0; }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    HIP_TRY(fn, hipDeviceSynchronize());                                     // a run in flight still reads the old list
+    HIP_TRY(fn, hipMemcpy(b->d_tiles, b->tiles.data(), b->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -22,13 +22,13 @@ struct TileDesc {
     uint32_t utt;
     uint32_t frame0;
     uint32_t nframes;
-    uint32_t pad;
+    uint32_t uid;               // the utterance's number for the dither generator: its index, or what speech_batch_set_ids gave
 };
 
 // Dither (c/kaldi_mfcc.c:243-262: a Box-Muller pair per two samples of every frame, drawn afresh for each frame).  The reference
 // seeds a serial generator from the wall clock; here the pair of samples (2i, 2i+1) of frame w of utterance u takes its
 // random bits from a counter-based hash, so any kernel shape draws the same noise:
-//   fk = mix64(mix64(seed ^ u << 32) + w * 0x100000001B3)            once per frame (64-bit, well mixed)
+//   fk = mix64(mix64(seed ^ uid << 32) + w * 0x100000001B3)            once per frame (64-bit, well mixed)
 //   h  = fmix32(lo32(fk) ^ i * 0x9E3779B9) + hi32(fk)                per pair: 32 bits, 8 instructions
 //   u1 = hi16(h) / 2^16,  u2 = lo16(h) / 2^16                        (65536 levels each: |noise| <= 4.7 sigma, ample for dither)
 #if defined(__HIPCC__)
@@ -116,6 +116,11 @@ struct FrameParams {
     const T *idft;               // [(P+1) x (B+2)]
     T *mel_out;                  // optional scratch [frames x B] (plp two-kernel path), else nullptr
 };
+
+// host layer (speech_api.hip), for host_pipeline.hip
+int fail(const char *fn, const char *fmt, ...);                             // records and prints "error in <fn>: ...", returns 1
+void plan_info(const speech_plan *p, int *device, int *dtype, size_t *D);
+int batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base);
 
 // corpus post-processing (post_kernels.hip)
 constexpr int POST_MAX_ORDER = 3, POST_MAX_WINDOW = 5, POST_MAX_TAPS = 2 * POST_MAX_ORDER * POST_MAX_WINDOW + 1;

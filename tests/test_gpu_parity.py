@@ -329,6 +329,45 @@ def test_batch_run_can_be_captured_in_a_graph(kind, o):
         assert bool((Yg == want).all())
 
 
+@pytest.mark.parametrize("kind,o", [("mfcc", {}), ("spectrogram", {}), ("fbank", dict(sr=8000.0, hif=4000.0, B=23)), ("mfcc", dict(force_generic=1))])
+def test_dither_follows_the_utterance_ids_not_the_batch(kind, o):
+    """a corpus cut into two batches (or sharded over ranks) gets the noise of the single batch once the batches carry the
+    utterances' corpus numbers (speech_batch_set_ids)"""
+    import torch
+    lens = [8000, 12000, 4000, 9000, 5000]
+    xs = [signals.utterance(n, 1400 + i, sr=o.get("sr", 16000.0)) for i, n in enumerate(lens)]
+
+    def run(idx, ids):
+        plan = api.Plan(kind, dither=1.0, **o)
+        b = api.Batch(plan, [lens[i] for i in idx])
+        if ids is not None:
+            b.set_ids(ids)
+        X = torch.from_numpy(np.concatenate([xs[i] for i in idx])).cuda()
+        Y = torch.zeros(b.total_out, device="cuda")
+        b.run(X, Y)
+        torch.cuda.synchronize()
+        y = Y.cpu().numpy()
+        return [y[int(b.y_off[k]):int(b.y_off[k]) + int(b.n_frames[k]) * plan.D] for k in range(len(idx))]
+
+    whole = run([0, 1, 2, 3, 4], None)
+    part_a, part_b = run([3, 0], [3, 0]), run([4, 2, 1], [4, 2, 1])
+    for k, i in enumerate([3, 0]):
+        assert np.array_equal(part_a[k], whole[i])
+    for k, i in enumerate([4, 2, 1]):
+        assert np.array_equal(part_b[k], whole[i])
+    # without the ids the second batch's first utterance draws utterance 0's noise, not its own
+    assert not np.array_equal(run([4, 2, 1], None)[0], whole[4])
+    # set_ids(None) restores the default
+    plan = api.Plan(kind, dither=1.0, **o)
+    b = api.Batch(plan, lens)
+    b.set_ids([9, 8, 7, 6, 5]); b.set_ids(None)
+    X = torch.from_numpy(np.concatenate(xs)).cuda()
+    Y = torch.zeros(b.total_out, device="cuda")
+    b.run(X, Y)
+    torch.cuda.synchronize()
+    assert np.array_equal(Y.cpu().numpy(), np.concatenate(whole))
+
+
 def test_dither_is_seeded_and_has_the_right_scale():
     import torch
     x = np.zeros(16000, dtype=np.float32)
@@ -391,6 +430,40 @@ def test_which_plans_run_on_the_tuned_kernels():
     for kind, o in generic:
         assert not api.Plan(kind, **o).tuned, (kind, o)
     assert not api.Plan("mfcc", dtype="f64").tuned
+
+
+@pytest.mark.parametrize("kind,o,dtype,pcm", [("mfcc", {}, "f32", False), ("spectrogram", dict(snip=0), "f32", False), ("fbank", dict(B=40, dither=1.0), "f32", False),
+                                               ("mfcc", dict(mn0=1, snip=0), "f64", False), ("plp", {}, "f32", True), ("fbank", dict(sr=8000.0, hif=4000.0, dither=0.5), "f64", True)])
+def test_run_host_equals_the_resident_batch(kind, o, dtype, pcm):
+    """speech_plan_run_host: host pointers in and out, chunked over two streams -- the features of the whole list as one
+    resident batch, bit for bit (dither included: the chunks carry the utterances' numbers), for any chunk size"""
+    import torch
+    rng = np.random.default_rng(5)
+    lens = [int(n) for n in rng.integers(400, 30000, size=23)] + [400, 160000, 401]
+    xs = [signals.utterance(n, 1500 + i, sr=o.get("sr", 16000.0)) for i, n in enumerate(lens)]
+    t = np.float32 if dtype == "f32" else np.float64
+    plan = api.Plan(kind, dtype=dtype, **o)
+    b = api.Batch(plan, lens)
+    td = torch.float32 if dtype == "f32" else torch.float64
+    X = torch.from_numpy(np.concatenate(xs)).to(td).cuda()
+    Y = torch.zeros(b.total_out, device="cuda", dtype=td)
+    b.run(X, Y)
+    torch.cuda.synchronize()
+    y = Y.cpu().numpy()
+    want = [y[int(b.y_off[u]):int(b.y_off[u]) + int(b.n_frames[u]) * plan.D].reshape(-1, plan.D) for u in range(len(lens))]
+    host_in = [x.astype(np.int16) if pcm else x.astype(t) for x in xs]
+    for chunk in (0, 1, 100000, 700000):                      # default (one chunk here), one utterance per chunk, a few, ragged
+        got = plan.run_host(host_in, chunk_bytes=chunk)
+        assert len(got) == len(want)
+        for u, (g, w) in enumerate(zip(got, want)):
+            assert g.dtype == t and np.array_equal(g, w), (chunk, u)
+    assert plan.run_host([]) == []
+    if o.get("snip", 1):
+        with pytest.raises(api.SpeechError):
+            plan.run_host([host_in[0], host_in[0][:100]], out=[np.zeros_like(want[0]), np.zeros((1, plan.D), t)])
+        assert np.array_equal(plan.run_host([host_in[0]])[0], want[0])          # and the pipeline still works afterwards
+    api._lib.load().speech_host_release()
+    assert np.array_equal(plan.run_host([host_in[0]])[0], want[0])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])

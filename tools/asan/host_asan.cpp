@@ -104,6 +104,20 @@ int main()
             (void)hipFree(dX); (void)hipFree(dY); (void)hipFree(dZ);
             speech_batch_destroy(b);
         }
+        // ragged list from host memory through the two-stream pipeline, one utterance per chunk and all in one
+        {
+            std::vector<const void *> xp; std::vector<void *> yp; std::vector<size_t> nn;
+            std::vector<std::vector<float>> outs;
+            for (size_t i = 0; i < 9; ++i) { nn.push_back(400 + 1777 * i); outs.emplace_back(((nn.back() + 80) / 160 + 1) * 13, 0.0f); }
+            for (size_t i = 0; i < 9; ++i) { xp.push_back(x.data() + 100 * i); yp.push_back(outs[i].data()); }
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 1) == 0);
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 0) == 0);
+            nn[4] = 0;
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 30000) == 1);       // an invalid utterance in a later chunk
+            nn[4] = 5000;
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 30000) == 0);
+            speech_host_release();
+        }
         // 16-bit PCM from host memory
         std::vector<short> x16(20000);
         for (size_t i = 0; i < x16.size(); ++i) { x16[i] = (short)x[i]; }
