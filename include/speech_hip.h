@@ -101,11 +101,13 @@ int speech_extract_pcm16(const speech_opts *opts, const short *X16_host, size_t 
    Y[u] at room for its W_u x D features (the plan's dtype).  The utterances are cut into chunks of about chunk_bytes of
    input (0 = 64 MiB; a chunk holds at least one utterance); each chunk is packed into pinned memory, copied, run as one
    batch and copied back on one of two streams, so that copies and packing overlap the kernels.  The features equal
-   speech_batch_run on the whole list bit for bit (dithered plans included).  Synchronous: Y is complete on return.  The
+   speech_batch_run on the whole list bit for bit (dithered plans included; ids, if not NULL, gives the utterances' numbers
+   for the dither generator as speech_batch_set_ids does -- a rank that holds a shard of a corpus passes the corpus
+   indices and gets the noise of the unsharded run).  Synchronous: Y is complete on return.  The
    staging buffers (device and pinned, about 2 x (chunk input + chunk output)) belong to the calling thread and are kept
    for later calls; speech_host_release frees them. */
 int speech_plan_run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t *n_samples, void *const *Y,
-                         int pcm16, size_t chunk_bytes);
+                         int pcm16, size_t chunk_bytes, const unsigned int *ids);
 void speech_host_release(void);
 
 /* Widening: corpus post-processing on a batch's packed features Y_dev (frame-major W x D per utterance,

@@ -97,7 +97,7 @@ def load():
     lib.speech_batch_splice_subsample.argtypes = [vp, vp, vp, i, i, i, i, vp]; lib.speech_batch_splice_subsample.restype = i
     lib.speech_batch_subsample_rows.argtypes = [vp, i, i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]; lib.speech_batch_subsample_rows.restype = i
     lib.speech_batch_set_ids.argtypes = [vp, C.POINTER(C.c_uint)]; lib.speech_batch_set_ids.restype = i
-    lib.speech_plan_run_host.argtypes = [vp, z, C.POINTER(vp), C.POINTER(z), C.POINTER(vp), i, z]; lib.speech_plan_run_host.restype = i
+    lib.speech_plan_run_host.argtypes = [vp, z, C.POINTER(vp), C.POINTER(z), C.POINTER(vp), i, z, C.POINTER(C.c_uint)]; lib.speech_plan_run_host.restype = i
     lib.speech_host_release.argtypes = []; lib.speech_host_release.restype = None
     lib.speech_extract_pcm16.argtypes = [C.POINTER(SpeechOpts), C.POINTER(C.c_short), z, vp]; lib.speech_extract_pcm16.restype = i
     _lib = lib

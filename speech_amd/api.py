@@ -145,9 +145,10 @@ class Plan:
             return None
         return W.value
 
-    def run_host(self, xs, chunk_bytes=0, out=None):
+    def run_host(self, xs, chunk_bytes=0, out=None, ids=None):
         """features of a list of utterances held in host memory (numpy arrays of the plan's dtype, or all int16 = 16-bit PCM),
-        as a list of W_u x D numpy arrays: speech_plan_run_host, chunked and overlapped host -> device -> host"""
+        as a list of W_u x D numpy arrays: speech_plan_run_host, chunked and overlapped host -> device -> host.  ids: the
+        utterances' numbers in the corpus, for the dither generator (default: their positions in xs)"""
         n = len(xs)
         pcm16 = n > 0 and all(np.asarray(x).dtype == np.int16 for x in xs)
         dt = np.int16 if pcm16 else self.np_dtype
@@ -162,7 +163,13 @@ class Plan:
         Xp = (C.c_void_p * max(1, n))(*[x.ctypes.data for x in xs])
         Yp = (C.c_void_p * max(1, n))(*[y.ctypes.data if y.size else xs[0].ctypes.data for y in ys])
         Np = (C.c_size_t * max(1, n))(*[x.size for x in xs])
-        if self._lib.speech_plan_run_host(self._h, n, Xp, Np, Yp, int(pcm16), int(chunk_bytes)) != 0:
+        idp = None
+        if ids is not None:
+            ida = np.ascontiguousarray(ids, dtype=np.uint32)
+            if ida.shape != (n,):
+                raise ValueError("ids must have one entry per utterance")
+            idp = ida.ctypes.data_as(C.POINTER(C.c_uint))
+        if self._lib.speech_plan_run_host(self._h, n, Xp, Np, Yp, int(pcm16), int(chunk_bytes), idp) != 0:
             raise SpeechError(_lib.last_error())
         return ys
 
@@ -326,6 +333,14 @@ def cmvn_from_stats(s, q, n, norm_vars=True, var_floor=1.0e-20):
     if norm_vars:
         scale = 1.0 / np.sqrt(np.maximum(q / float(n) - mean * mean, var_floor))
     return scale, -mean * scale
+
+
+def extract_shard(plan, xs, rank, world_size, chunk_bytes=0):
+    """This rank's part of a corpus held in host memory: (indices, features) of the utterances shard_utterances gives to
+    `rank`, extracted with speech_plan_run_host under their corpus numbers -- so the union over the ranks equals the
+    single-GPU run bit for bit, dither included, whatever the world size.  No communication."""
+    idx = shard_utterances([np.asarray(x).size for x in xs], world_size)[rank]
+    return idx, plan.run_host([xs[i] for i in idx], chunk_bytes=chunk_bytes, ids=idx)
 
 
 def shard_utterances(n_samples, world_size):

@@ -111,7 +111,7 @@ int drain(const char *fn, Slot &k, void *const *Y, size_t es, size_t D)
     return 0;
 }
 
-int run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t *n_samples, void *const *Y, int pcm16, size_t chunk_bytes)
+int run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t *n_samples, void *const *Y, int pcm16, size_t chunk_bytes, const unsigned int *ids)
 {
     const char *fn = "speech_plan_run_host";
     int dev = 0, dtype = 0; size_t D = 0;
@@ -138,7 +138,7 @@ int run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t 
             ++count;
         }
         if (first + count > 0xFFFFFFFFull) { return fail(fn, "too many utterances"); }
-        if (batch_create(&k.batch, plan, count, n_samples + first, nullptr, nullptr, (uint32_t)first)) { return 1; }
+        if (batch_create(&k.batch, plan, count, n_samples + first, nullptr, nullptr, (uint32_t)first, ids ? ids + first : nullptr)) { return 1; }
         k.first = first; k.count = count;
         k.y_off.resize(count); k.frames.resize(count);
         std::vector<size_t> x_off(count);
@@ -171,7 +171,8 @@ int run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t 
 
 extern "C" {
 
-int speech_plan_run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t *n_samples, void *const *Y, int pcm16, size_t chunk_bytes)
+int speech_plan_run_host(speech_plan *plan, size_t nutt, const void *const *X, const size_t *n_samples, void *const *Y, int pcm16, size_t chunk_bytes,
+                         const unsigned int *ids)
 {
     using namespace speech;
     const char *fn = "speech_plan_run_host";
@@ -183,7 +184,7 @@ int speech_plan_run_host(speech_plan *plan, size_t nutt, const void *const *X, c
     plan_info(plan, &dev, nullptr, nullptr);
     if (hipGetDevice(&prev) != hipSuccess) { prev = -1; }
     if (hipSetDevice(dev) != hipSuccess) { return fail(fn, "cannot select device %d", dev); }
-    int rc = run_host(plan, nutt, X, n_samples, Y, pcm16, chunk_bytes);
+    int rc = run_host(plan, nutt, X, n_samples, Y, pcm16, chunk_bytes, ids);
     if (rc)
     {
         // leave nothing in flight: wait for both streams and drop the chunks' batches

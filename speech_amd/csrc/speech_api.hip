@@ -531,13 +531,14 @@ int speech_plan_num_frames(const speech_plan *p, size_t N, size_t *W)
 
 int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off)
 {
-    return speech::batch_create(out, p, nutt, n_samples, x_off, y_off, 0u);
+    return speech::batch_create(out, p, nutt, n_samples, x_off, y_off, 0u, nullptr);
 }
 
 }  // extern "C"
 
-// uid_base: the dither number of the batch's first utterance (utterance u draws its noise as utterance uid_base + u)
-int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base)
+// utterance u draws its dither as utterance number uids[u], or uid_base + u when uids is null
+int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base,
+                         const unsigned int *uids)
 {
     const char *fn = "speech_batch_create";
     if (!out || !p || (nutt && !n_samples)) { return fail(fn, "null argument"); }
@@ -565,7 +566,7 @@ int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const 
         b->total_samples += N; b->total_out += W * p->sz.D; b->total_frames += W;
         for (size_t f0 = 0; f0 < W; f0 += (size_t)tile)
         {
-            TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.uid = uid_base + (uint32_t)u;
+            TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.uid = uids ? (uint32_t)uids[u] : uid_base + (uint32_t)u;
             b->tiles.push_back(t);
         }
     }

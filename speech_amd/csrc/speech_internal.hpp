@@ -120,7 +120,8 @@ struct FrameParams {
 // host layer (speech_api.hip), for host_pipeline.hip
 int fail(const char *fn, const char *fmt, ...);                             // records and prints "error in <fn>: ...", returns 1
 void plan_info(const speech_plan *p, int *device, int *dtype, size_t *D);
-int batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base);
+int batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base,
+                 const unsigned int *uids);
 
 // corpus post-processing (post_kernels.hip)
 constexpr int POST_MAX_ORDER = 3, POST_MAX_WINDOW = 5, POST_MAX_TAPS = 2 * POST_MAX_ORDER * POST_MAX_WINDOW + 1;

@@ -466,6 +466,25 @@ def test_run_host_equals_the_resident_batch(kind, o, dtype, pcm):
     assert np.array_equal(plan.run_host([host_in[0]])[0], want[0])
 
 
+@pytest.mark.parametrize("o", [dict(), dict(dither=1.0)])
+def test_sharded_extraction_is_independent_of_the_world_size(o):
+    """the ranks' shards (api.extract_shard: LPT assignment, no communication) together give the single-GPU features bit for
+    bit for world sizes 1, 2, 3 and 8 -- the ranks are run one after the other here"""
+    rng = np.random.default_rng(9)
+    lens = [int(n) for n in rng.integers(400, 20000, size=19)]
+    xs = [signals.utterance(n, 1600 + i) for i, n in enumerate(lens)]
+    plan = api.Plan("mfcc", **o)
+    whole = plan.run_host(xs)
+    for world in (1, 2, 3, 8):
+        seen = set()
+        for rank in range(world):
+            idx, feats = api.extract_shard(plan, xs, rank, world, chunk_bytes=200000)
+            for i, f in zip(idx, feats):
+                assert np.array_equal(f, whole[int(i)]), (world, rank, i)
+                seen.add(int(i))
+        assert seen == set(range(len(xs)))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_extract_pcm16_equals_the_drop_in_call(dtype):
     """speech_extract_pcm16 (host int16 in, host features out) = the drop-in call on the same samples as floats; same errors"""

@@ -110,12 +110,12 @@ int main()
             std::vector<std::vector<float>> outs;
             for (size_t i = 0; i < 9; ++i) { nn.push_back(400 + 1777 * i); outs.emplace_back(((nn.back() + 80) / 160 + 1) * 13, 0.0f); }
             for (size_t i = 0; i < 9; ++i) { xp.push_back(x.data() + 100 * i); yp.push_back(outs[i].data()); }
-            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 1) == 0);
-            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 0) == 0);
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 1, nullptr) == 0);
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 0, nullptr) == 0);
             nn[4] = 0;
-            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 30000) == 1);       // an invalid utterance in a later chunk
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 30000, nullptr) == 1);       // an invalid utterance in a later chunk
             nn[4] = 5000;
-            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 30000) == 0);
+            EXPECT(speech_plan_run_host(plan, 9, xp.data(), nn.data(), yp.data(), 0, 30000, nullptr) == 0);
             speech_host_release();
         }
         // 16-bit PCM from host memory
