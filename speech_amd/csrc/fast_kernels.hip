@@ -208,9 +208,7 @@ void fast_tables_destroy(FastTables *t)
     delete t;
 }
 
-size_t fast_scratch_elems(const FastTables *, size_t) { return 0; }
-
-hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, float *, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     if (fp.ntiles == 0) { return hipSuccess; }
     FastParams p;

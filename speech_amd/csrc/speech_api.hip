@@ -31,9 +31,7 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t stp, size_
                                const std::vector<int> &num, const std::vector<float> &dct, const std::vector<float> &lift,
                                const std::vector<float> &eql, const std::vector<float> &idft, std::string *err);
 void fast_tables_destroy(FastTables *t);
-size_t fast_scratch_elems(const FastTables *t, size_t total_frames);
-hipError_t launch_fast(const FastTables *t, const FrameParams<float> &p, float *scratch, hipStream_t s,
-                       hipEvent_t ev0, hipEvent_t ev1);
+hipError_t launch_fast(const FastTables *t, const FrameParams<float> &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 static thread_local std::string g_err;
 
@@ -246,7 +244,6 @@ struct speech_batch {
     std::vector<TileDesc> tiles;
     UttDesc *d_utts;
     TileDesc *d_tiles;
-    float *d_scratch;
     double *d_mom;               // post-processing: [nutt][2][D] moments, then [2][D] scale / offset (allocated on first use)
     unsigned long long *d_zrow;  // splice + subsample: first output row of each utterance for (zrow_n, zrow_off); allocated on first use
     std::vector<unsigned long long> zrow;
@@ -345,7 +342,6 @@ void fill_params(const speech_batch *b, const void *X, const short *X16, void *Y
     fp->compress = (T)o.compress;
     fp->compress_mode = ((T)o.compress == (T)1) ? 1 : (((T)o.compress == (T)0.5) ? 2 : 0);       // c/kaldi_plp.c:341,347
     fp->eql = (const T *)p->d_eql; fp->idft = (const T *)p->d_idft;
-    fp->mel_out = nullptr;
 }
 
 // shared by mn0 and the post-processing entry points
@@ -412,7 +408,7 @@ int batch_run(speech_batch *b, const void *X, const short *X16, void *Y, void *s
     else
     {
         FrameParams<float> fp; fill_params<float>(b, X, X16, Y, &fp);
-        if (p->tuned) { HIP_TRY(fn, launch_fast(p->fast, fp, b->d_scratch, s, e0, e1)); }
+        if (p->tuned) { HIP_TRY(fn, launch_fast(p->fast, fp, s, e0, e1)); }
         else
         {
             if (e0) { HIP_TRY(fn, hipEventRecord(e0, s)); }
@@ -546,7 +542,7 @@ int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const 
     if (nutt > 0xFFFFFFFFull) { return fail(fn, "too many utterances"); }
     speech_batch *b = new (std::nothrow) speech_batch();
     if (!b) { return fail(fn, "out of host memory"); }
-    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_scratch = nullptr; b->d_mom = nullptr; b->d_zrow = nullptr; b->zrow_n = b->zrow_off = -1; b->yoff_pow2 = -1; b->ev0 = b->ev1 = nullptr;
+    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_mom = nullptr; b->d_zrow = nullptr; b->zrow_n = b->zrow_off = -1; b->yoff_pow2 = -1; b->ev0 = b->ev1 = nullptr;
     b->total_samples = b->total_out = b->total_frames = 0;
     const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : GENERIC_TILE_FRAMES;
     const char *kfn = kind_name(p->o.kind, p->o.dtype);
@@ -578,11 +574,6 @@ int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const 
     if (e == hipSuccess && nutt) { e = hipMemcpy(b->d_utts, b->utts.data(), nutt * sizeof(UttDesc), hipMemcpyHostToDevice); }
     if (e == hipSuccess && !b->tiles.empty()) { e = hipMalloc((void **)&b->d_tiles, b->tiles.size() * sizeof(TileDesc)); }
     if (e == hipSuccess && !b->tiles.empty()) { e = hipMemcpy(b->d_tiles, b->tiles.data(), b->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice); }
-    if (e == hipSuccess && p->tuned)
-    {
-        const size_t ns = fast_scratch_elems(p->fast, b->total_frames);
-        if (ns) { e = hipMalloc((void **)&b->d_scratch, ns * sizeof(float)); }
-    }
     if (e != hipSuccess) { speech_batch_destroy(b); return fail(fn, "device allocation failed: %s", hipGetErrorString(e)); }
     *out = b;
     return 0;
@@ -603,7 +594,6 @@ void speech_batch_destroy(speech_batch *b)
     DeviceGuard g(b->plan ? b->plan->device : 0);
     if (b->d_utts) { (void)hipFree(b->d_utts); }
     if (b->d_tiles) { (void)hipFree(b->d_tiles); }
-    if (b->d_scratch) { (void)hipFree(b->d_scratch); }
     if (b->d_mom) { (void)hipFree(b->d_mom); }
     if (b->d_zrow) { (void)hipFree(b->d_zrow); }
     if (b->ev0) { (void)hipEventDestroy(b->ev0); }

@@ -114,7 +114,6 @@ struct FrameParams {
     int compress_mode;           // 0 pow, 1 identity, 2 sqrt
     const T *eql;                // [B]
     const T *idft;               // [(P+1) x (B+2)]
-    T *mel_out;                  // optional scratch [frames x B] (plp two-kernel path), else nullptr
 };
 
 // host layer (speech_api.hip), for host_pipeline.hip
