@@ -19,6 +19,9 @@
 // channel, default 0); the samples go to the device as int16 (speech_extract_pcm16, include/speech_hip.h) and keep their
 // integer scale, as Kaldi's wave reader leaves them.  The sample rate comes from the header unless -r is given, and an
 // -r that contradicts the header is an error.  The output is float32.
+// --wav_scp=<file> takes a Kaldi wav.scp ("<utt-id> <path to .wav>" per line; no pipes) instead of one input file and writes
+// every utterance's features into one archive (-o, with --scp the matching script file): the whole list goes through
+// speech_plan_run_host in groups, int16 over PCIe, the usage of compute-mfcc-feats scp:wav.scp ark,scp:feats.ark,feats.scp.
 #include <cctype>
 #include <cfloat>
 #include <cstdint>
@@ -31,6 +34,7 @@
 #include <iostream>
 #include <string>
 #include <unistd.h>
+#include <utility>
 #include <vector>
 #include "../include/codee_speech.h"
 #include "../include/speech_hip.h"
@@ -137,6 +141,95 @@ static bool read_wav(istream &is, const char magic[8], unsigned channel, WavInfo
     }
 }
 
+static void put_ark_header(ostream &os, const string &key, bool f64, size_t W, size_t D)
+{
+    // Kaldi binary matrix entry, always frame-major (W x D)
+    const int32_t rows = (int32_t)W, cols = (int32_t)D;
+    os << key << ' ';
+    os.put('\0'); os.put('B'); os.write(f64 ? "DM " : "FM ", 3);
+    os.put('\4'); os.write((const char *)&rows, 4); os.put('\4'); os.write((const char *)&cols, 4);
+}
+
+// --wav_scp: every line's .wav through the plan, in groups of at most `group_samples` samples, into one archive
+static int run_wav_scp(const string &list, const speech_opts &o_in, bool have_r, unsigned channel, ostream &os, long long ark_off, const string &ofile,
+                       const string &scp_file, size_t group_samples)
+{
+    ifstream ls(list);
+    if (!ls) { FAIL("problem opening the wav_scp file"); }
+    struct Item { string key; WavInfo wav; };
+    vector<pair<string, string>> entries;
+    string line;
+    while (getline(ls, line))
+    {
+        const size_t a = line.find_first_not_of(" \t");
+        if (a == string::npos) { continue; }
+        const size_t b = line.find_first_of(" \t", a);
+        if (b == string::npos) { FAIL("wav_scp line without a path: " + line); }
+        const size_t c = line.find_first_not_of(" \t", b), e = line.find_last_not_of(" \t\r");
+        if (c == string::npos) { FAIL("wav_scp line without a path: " + line); }
+        const string path = line.substr(c, e - c + 1);
+        if (!path.empty() && path.back() == '|') { FAIL("wav_scp pipes are not supported: " + line); }
+        entries.emplace_back(line.substr(a, b - a), path);
+    }
+    if (entries.empty()) { FAIL("the wav_scp file lists no utterances"); }
+    ofstream scp;
+    if (!scp_file.empty()) { scp.open(scp_file, ios::app); if (!scp) { FAIL("problem opening scp file"); } }
+    speech_opts o = o_in;
+    speech_plan *plan = nullptr;
+    size_t D = 0, done = 0;
+    while (done < entries.size())
+    {
+        vector<Item> items;
+        size_t total = 0;
+        while (done + items.size() < entries.size() && (items.empty() || total < group_samples))
+        {
+            const auto &en = entries[done + items.size()];
+            ifstream f(en.second, ios::binary);
+            if (!f) { FAIL("problem opening input file " + en.second); }
+            Item it; it.key = en.first;
+            char magic[8]; string why;
+            if (!f.read(magic, 8) || !read_wav(f, magic, channel, it.wav, why)) { FAIL("problem reading .wav input " + en.second + ": " + why); }
+            if (it.wav.x.empty()) { FAIL("input (X) found to be empty: " + en.second); }
+            if (!plan)
+            {
+                if (have_r && o.sr != (double)it.wav.rate) { FAIL("srate (sample rate) does not match the .wav header (" + to_string(it.wav.rate) + " Hz): " + en.second); }
+                o.sr = (double)it.wav.rate;
+                if (o.kind != SPEECH_SPECTROGRAM && o_in.hif < DBL_EPSILON) { o.hif = 0.5 * o.sr + o_in.hif; }
+                if (o.kind != SPEECH_SPECTROGRAM && o.hif <= o.lof) { FAIL("hif must be > lof"); }
+                if (speech_plan_create(&plan, &o, 0)) { FAIL("problem during function call"); }
+                speech_plan_sizes(plan, nullptr, nullptr, nullptr, &D, nullptr);
+            }
+            else if ((double)it.wav.rate != o.sr) { speech_plan_destroy(plan); FAIL("sample rate differs from the first file's: " + en.second); }
+            total += it.wav.x.size();
+            items.push_back(std::move(it));
+        }
+        const size_t n = items.size();
+        vector<const void *> xp(n); vector<void *> yp(n); vector<size_t> nn(n), ww(n); vector<unsigned> ids(n);
+        vector<vector<float>> ys(n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            nn[i] = items[i].wav.x.size();
+            if (speech_plan_num_frames(plan, nn[i], &ww[i])) { speech_plan_destroy(plan); FAIL("frame length must be < signal length if snip_edges: " + items[i].key); }
+            ys[i].resize(ww[i] * D + 1);
+            xp[i] = items[i].wav.x.data(); yp[i] = ys[i].data(); ids[i] = (unsigned)(done + i);
+        }
+        if (speech_plan_run_host(plan, n, xp.data(), nn.data(), yp.data(), 1, 0, ids.data())) { speech_plan_destroy(plan); FAIL("problem during function call"); }
+        for (size_t i = 0; i < n; ++i)
+        {
+            put_ark_header(os, items[i].key, false, ww[i], D);
+            os.write((const char *)ys[i].data(), (streamsize)(ww[i] * D * sizeof(float)));
+            if (!os) { speech_plan_destroy(plan); FAIL("problem writing output file (Y)"); }
+            if (scp.is_open()) { scp << items[i].key << ' ' << ofile << ':' << (ark_off + (long long)items[i].key.size() + 1) << '\n'; }
+            ark_off += (long long)items[i].key.size() + 1 + 15 + (long long)(ww[i] * D * sizeof(float));
+        }
+        done += n;
+    }
+    os.flush();
+    speech_plan_destroy(plan);
+    if (scp.is_open() && !scp) { FAIL("problem writing scp file"); }
+    return 0;
+}
+
 static bool write_npy_header(ostream &os, bool f64, bool fortran, size_t r, size_t c)
 {
     string d = string("{'descr': '") + (f64 ? "<f8" : "<f4") + "', 'fortran_order': " + (fortran ? "True" : "False") + ", 'shape': (" + to_string(r) + ", " + to_string(c) + "), }";
@@ -190,6 +283,7 @@ static void usage()
     printf(fmt, "--append", "with --ark: append to the archive instead of replacing it");
     printf(fmt, "--scp=<file>", "with --ark and -o: append \"<utt-id> <ofile>:<offset>\" to this script file");
     printf(fmt, "--channel=<n>", "with a .wav input: the channel to use [default=0]");
+    printf(fmt, "--wav_scp=<file>", "list of \"<utt-id> <.wav path>\" lines instead of <file>; -o is a Kaldi archive");
     printf(fmt, "-h, --help", "display this help and exit");
     cout << "\nMakes Kaldi " << (TOOL == TOOL_SPECTROGRAM ? "spectrogram" : TOOL == TOOL_FBANK ? "mel-fbank" : TOOL == TOOL_MFCC ? "MFCC" : "PLP")
          << " features for univariate, real-valued X on an AMD MI355X (libspeech.so).\n"
@@ -205,7 +299,7 @@ int main(int argc, char *argv[])
     double sr = 16000.0, fl = 25.0, shft = 10.0, d = 0.1, p = 0.97, lof = 20.0, hif = 0.0, Q = 22.0, compress = 1.0 / 3.0, cep_scale = 1.0;
     long Bi = 23, Ci = 13, channel = 0;
     int snipe = 0, dc0 = 0, rawe = 0, amp = 0, lg = 0, usee = 0, mn0 = 0, help = 0;
-    string wintype = "povey", ofile, ark_key, scp_file;
+    string wintype = "povey", ofile, ark_key, scp_file, wav_scp;
     bool have_o = false, append = false, have_r = false;
 
     static const option longopts[] = {
@@ -216,7 +310,7 @@ int main(int argc, char *argv[])
         {"B", required_argument, nullptr, 'b'}, {"log", no_argument, nullptr, 'g'}, {"C", required_argument, nullptr, 'c'}, {"Q", required_argument, nullptr, 'q'},
         {"use_energy", no_argument, nullptr, 'x'}, {"zero_mean", no_argument, nullptr, 'm'}, {"ofile", required_argument, nullptr, 'o'},
         {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001},
-        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {nullptr, 0, nullptr, 0}};
+        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {"wav_scp", required_argument, nullptr, 1006}, {nullptr, 0, nullptr, 0}};
     const char *shortopts = TOOL == TOOL_SPECTROGRAM ? "r:t:s:ed:zyp:w:mo:h" : TOOL == TOOL_FBANK ? "r:t:s:ed:zyp:w:al:u:b:gxmo:h" : "r:t:s:ed:zyp:w:l:u:b:c:q:xmo:h";
     int c, nerrs = 0;
     opterr = 0;
@@ -239,6 +333,7 @@ int main(int argc, char *argv[])
             case 1002: ark_key = optarg; break;
             case 1003: scp_file = optarg; break;
             case 1004: append = true; break;
+            case 1006: wav_scp = optarg; break;
             case 1005: channel = strtol(optarg, &end, 10); if (end == optarg || *end || channel < 0) { ++nerrs; } break;
             default: ++nerrs; cerr << prog() << ": invalid option \"" << argv[optind - 1] << "\"" << endl; break;
         }
@@ -248,21 +343,24 @@ int main(int argc, char *argv[])
     if (argc - optind > 1) { FAIL("too many input files"); }
     const string ifile = (optind < argc) ? argv[optind] : "";
 
+    const bool list_mode = !wav_scp.empty();
+    if (list_mode && !ifile.empty()) { FAIL("--wav_scp replaces the input file"); }
     // stdin / stdout detection: src/kaldi_mfcc.cpp:151-159
-    const bool stdi1 = ifile.empty() || ifile == "-";
+    const bool stdi1 = !list_mode && (ifile.empty() || ifile == "-");
     if (stdi1 && isatty(fileno(stdin))) { FAIL("no stdin detected"); }
     const bool stdo1 = have_o ? (ofile.empty() || ofile == "-") : !isatty(fileno(stdout));
     const bool wo1 = stdo1 || have_o;
 
     ifstream ifs1;
-    if (!stdi1) { ifs1.open(ifile, ios::binary); if (!ifs1) { FAIL("problem opening input file"); } }
+    if (!stdi1 && !list_mode) { ifs1.open(ifile, ios::binary); if (!ifs1) { FAIL("problem opening input file"); } }
     istream &is = stdi1 ? cin : ifs1;
     NpyInfo i1;
     WavInfo wav;
-    char magic[8];
-    if (!is.read(magic, 8)) { FAIL("problem reading header for input file"); }
+    char magic[8] = {0};
+    if (!list_mode && !is.read(magic, 8)) { FAIL("problem reading header for input file"); }
     const bool is_wav = memcmp(magic, "RIFF", 4) == 0;
-    if (is_wav)
+    if (list_mode) { }
+    else if (is_wav)
     {
         string why;
         if (!read_wav(is, magic, (unsigned)channel, wav, why)) { FAIL("problem reading .wav input: " + why); }
@@ -284,8 +382,10 @@ int main(int argc, char *argv[])
     if (TOOL != TOOL_SPECTROGRAM)
     {
         if (lof < 0.0) { FAIL("lof must be nonnegative"); }
+        const double hif_arg = hif;
         if (hif < DBL_EPSILON) { hif = 0.5 * sr + hif; }                                     // offset from Nyquist
-        if (hif <= lof) { FAIL("hif must be > lof"); }
+        if (hif <= lof && !(list_mode && !have_r)) { FAIL("hif must be > lof"); }            // (a list without -r: checked once the first header gives the rate)
+        if (list_mode) { hif = hif_arg; }
         if (Bi < 1) { FAIL("B must be positive"); }
         B = (size_t)Bi;
     }
@@ -295,6 +395,30 @@ int main(int argc, char *argv[])
         C = (size_t)Ci;
         if (C > B) { FAIL("C (num ceps) must be <= B (num fbank bins)"); }
         if (Q < 0.0) { FAIL("Q must be nonnegative"); }
+    }
+
+    auto make_opts = [&](speech_opts &o) {
+        speech_opts_default(&o, TOOL == TOOL_SPECTROGRAM ? SPEECH_SPECTROGRAM : TOOL == TOOL_FBANK ? SPEECH_FBANK : TOOL == TOOL_MFCC ? SPEECH_MFCC : SPEECH_PLP);
+        o.dtype = SPEECH_F32; o.sr = sr; o.frame_length = fl; o.frame_shift = shft; o.snip_edges = snipe; o.dither = d; o.dc0 = dc0; o.raw_energy = rawe;
+        o.preemph = p; o.mn0 = mn0; o.amp = amp; o.lof = lof; o.hif = hif; o.B = B; o.lg = lg; o.use_energy = usee; o.C = C; o.Q = Q;
+        o.compress = compress; o.cep_scale = cep_scale; o.lpc_order = 0;
+        strncpy(o.win_type, wintype.c_str(), sizeof(o.win_type) - 1); o.win_type[sizeof(o.win_type) - 1] = '\0';
+    };
+    if (list_mode)
+    {
+        if (!ark_key.empty()) { FAIL("--wav_scp takes the utterance ids from the list, not from --ark"); }
+        if (!have_o || ofile.empty() || ofile == "-") { FAIL("--wav_scp needs an output archive (-o)"); }
+        ofstream ofs(ofile, append ? (ios::binary | ios::app) : (ios::binary | ios::trunc));
+        if (!ofs) { FAIL("problem opening output file 1"); }
+        long long off = 0;
+        if (append) { ofs.seekp(0, ios::end); off = (long long)ofs.tellp(); }
+        speech_opts o; make_opts(o);
+        timespec tic, toc;
+        clock_gettime(CLOCK_REALTIME, &tic);
+        if (run_wav_scp(wav_scp, o, have_r, (unsigned)channel, ofs, off, ofile, scp_file, (size_t)64 << 20)) { return 1; }
+        clock_gettime(CLOCK_REALTIME, &toc);
+        if (TOOL != TOOL_SPECTROGRAM) { cerr << "elapsed time = " << double(toc.tv_sec - tic.tv_sec) * 1e3 + double(toc.tv_nsec - tic.tv_nsec) / 1e6 << " ms" << endl; }
+        return 0;
     }
 
     // checks: src/kaldi_mfcc.cpp:250-251
@@ -326,12 +450,8 @@ int main(int argc, char *argv[])
     ostream &os = stdo1 ? cout : ofs1;
     if (wo1 && ark)
     {
-        // Kaldi binary matrix entry, always frame-major (W x D)
-        const int32_t rows = (int32_t)W, cols = (int32_t)D;
-        os << ark_key << ' ';
+        put_ark_header(os, ark_key, i1.f64, W, D);
         ark_off += (long long)ark_key.size() + 1;                                            // the scp offset points at the "\0B"
-        os.put('\0'); os.put('B'); os.write(i1.f64 ? "DM " : "FM ", 3);
-        os.put('\4'); os.write((const char *)&rows, 4); os.put('\4'); os.write((const char *)&cols, 4);
         if (!os) { FAIL("problem writing header for output file 1"); }
     }
     else if (wo1 && !write_npy_header(os, i1.f64, i1.fortran, i1.fortran ? D : W, i1.fortran ? W : D)) { FAIL("problem writing header for output file 1"); }
@@ -341,12 +461,7 @@ int main(int argc, char *argv[])
     int rc;
     if (is_wav)
     {
-        speech_opts o;
-        speech_opts_default(&o, TOOL == TOOL_SPECTROGRAM ? SPEECH_SPECTROGRAM : TOOL == TOOL_FBANK ? SPEECH_FBANK : TOOL == TOOL_MFCC ? SPEECH_MFCC : SPEECH_PLP);
-        o.dtype = SPEECH_F32; o.sr = sr; o.frame_length = fl; o.frame_shift = shft; o.snip_edges = snipe; o.dither = d; o.dc0 = dc0; o.raw_energy = rawe;
-        o.preemph = p; o.mn0 = mn0; o.amp = amp; o.lof = lof; o.hif = hif; o.B = B; o.lg = lg; o.use_energy = usee; o.C = C; o.Q = Q;
-        o.compress = compress; o.cep_scale = cep_scale; o.lpc_order = 0;
-        strncpy(o.win_type, wintype.c_str(), sizeof(o.win_type) - 1); o.win_type[sizeof(o.win_type) - 1] = '\0';
+        speech_opts o; make_opts(o);
         vector<float> Y(W * D + 1);
         rc = speech_extract_pcm16(&o, wav.x.data(), N, Y.data());
         if (rc) { FAIL("problem during function call"); }

@@ -223,3 +223,60 @@ def test_wav_input_matches_float_input(tmp_path):
     from speech_amd import ark
     (key, _, m), = list(ark.read_ark(str(tmp_path / "p.ark")))
     assert key == "utt1" and np.array_equal(m, api.kaldi_plp(xf))
+
+
+def test_wav_scp_validates_on_cpu(tmp_path):
+    x = signals.utterance(4000, 3).astype(np.int16)
+    w = tmp_path / "a.wav"
+    w.write_bytes(_wav_bytes(x))
+    lst = tmp_path / "wav.scp"
+    cases = [("utt1 %s\n" % w, ("-o", "-"), "--wav_scp needs an output archive"), ("utt1 %s\n" % w, (), "--wav_scp needs an output archive"),
+             ("utt1 %s\n" % w, ("--ark=k", "-o", str(tmp_path / "o.ark")), "takes the utterance ids from the list"),
+             ("utt1 sox %s -t wav - |\n" % w, ("-o", str(tmp_path / "o.ark")), "pipes are not supported"),
+             ("utt1\n", ("-o", str(tmp_path / "o.ark")), "line without a path"), ("\n\n", ("-o", str(tmp_path / "o.ark")), "lists no utterances"),
+             ("utt1 %s\n" % (tmp_path / "missing.wav"), ("-o", str(tmp_path / "o.ark")), "problem opening input file"),
+             ("utt1 %s\n" % w, ("-r", "8000", "-o", str(tmp_path / "o.ark")), "does not match the .wav header (16000 Hz)")]
+    for i, (text, args, msg) in enumerate(cases):
+        lst.write_text(text)
+        r = run("kaldi_mfcc", "-d0", "--wav_scp=%s" % lst, *args)
+        assert r.returncode == 1 and msg in r.stderr.decode(), (i, r.stderr)
+    r = run("kaldi_mfcc", "-d0", "--wav_scp=%s" % lst, str(w), "-o", str(tmp_path / "o.ark"))
+    assert r.returncode == 1 and "--wav_scp replaces the input file" in r.stderr.decode()
+    r = run("kaldi_mfcc", "-d0", "--wav_scp=%s" % (tmp_path / "nolist"), "-o", str(tmp_path / "o.ark"))
+    assert r.returncode == 1 and "problem opening the wav_scp file" in r.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_wav_scp_to_archive(tmp_path):
+    """the compute-mfcc-feats use: a wav.scp in, one archive + scp out, every entry equal to the single-file run"""
+    from speech_amd import api, ark
+    lens = [12000, 400, 30000, 8001]
+    xs = [signals.utterance(n, 90 + i).astype(np.int16) for i, n in enumerate(lens)]
+    lines = []
+    for i, x in enumerate(xs):
+        f = tmp_path / ("u%d.wav" % i)
+        f.write_bytes(_wav_bytes(x, extra_chunk=bool(i & 1)))
+        lines.append("utt%d   %s  " % (i, f))
+    lst = tmp_path / "wav.scp"
+    lst.write_text("\n".join(lines) + "\n\n")
+    out, scp = tmp_path / "feats.ark", tmp_path / "feats.scp"
+    r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "-b", "40", "-c", "20", "--wav_scp=%s" % lst, "-o", str(out), "--scp=%s" % scp)
+    assert r.returncode == 0, r.stderr
+    assert b"elapsed time = " in r.stderr
+    got = list(ark.read_ark(str(out)))
+    assert [k for k, _, _ in got] == ["utt%d" % i for i in range(4)]
+    for (k, off, m), x in zip(got, xs):
+        assert np.array_equal(m, api.kaldi_mfcc(x.astype(np.float32), B=40, C=20)), k
+    by_scp = list(ark.read_scp(str(scp)))                     # follows "<utt-id> <ark>:<offset>"
+    assert [k for k, _ in by_scp] == [k for k, _, _ in got] and all(np.array_equal(a[1], b[2]) for a, b in zip(by_scp, got))
+    # --append adds to the archive with correct offsets; default hif = Nyquist of the files' rate; dither (default 0.1) reproducible
+    r = run("kaldi_fbank", "-g", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f.ark"))
+    r2 = run("kaldi_fbank", "-g", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f2.ark"))
+    assert r.returncode == 0 and r2.returncode == 0, r.stderr
+    assert (tmp_path / "f.ark").read_bytes() == (tmp_path / "f2.ark").read_bytes()
+    r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "-b", "40", "-c", "20", "--append", "--wav_scp=%s" % lst, "-o", str(out), "--scp=%s" % scp)
+    assert r.returncode == 0, r.stderr
+    again = list(ark.read_ark(str(out)))
+    assert len(again) == 8 and all(np.array_equal(again[i][2], again[i + 4][2]) for i in range(4))
+    by_scp = list(ark.read_scp(str(scp)))
+    assert len(by_scp) == 8 and all(np.array_equal(a[1], b[2]) for a, b in zip(by_scp, again))
