@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -68,3 +69,48 @@ def test_shard_is_deterministic_and_never_splits_an_utterance():
     assert all(np.array_equal(x, y) for x, y in zip(p1, p2))
     assert sorted(np.concatenate(p1).tolist()) == list(range(6))
     assert api.shard_utterances(lens, 1)[0].tolist() == list(range(6))
+
+
+@pytest.mark.gpu
+def test_corpus_extraction_two_ranks_on_the_gpu(tmp_path):
+    """examples/extract_corpus.py as two processes (torch.distributed.run, both on GPU 0, gloo for the one all-reduce):
+    the ranks' archives together hold the single-process features bit for bit -- dither on, so the noise follows the
+    utterance, not the rank -- and the corpus-wide CMVN of both runs agrees"""
+    import subprocess
+    import sys
+    import wave
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import signals
+    from speech_amd import ark
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    lines = []
+    for i, n in enumerate([16000, 4000, 30000, 8000, 12000, 2000, 20000]):
+        p = tmp_path / ("u%d.wav" % i)
+        with wave.open(str(p), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(signals.utterance(n, 700 + i).astype(np.int16).tobytes())
+        lines.append("utt%d %s" % (i, p))
+    lst = tmp_path / "wav.scp"
+    lst.write_text("\n".join(lines) + "\n")
+    script = os.path.join(root, "examples", "extract_corpus.py")
+    common = [str(lst), "--kind", "mfcc", "--cmvn", "--opt", "dither=1.0", "--opt", "snip_edges=0"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, script, common[0], str(tmp_path / "one")] + common[1:], capture_output=True, env=env, timeout=300)
+    assert r1.returncode == 0, r1.stderr.decode()[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29541", script, common[0], str(tmp_path / "two")] + common[1:], capture_output=True, env=env, timeout=300)
+    assert r2.returncode == 0, r2.stderr.decode()[-2000:]
+    one = {k: m for k, _, m in ark.read_ark(str(tmp_path / "one" / "feats.0.ark"))}
+    two = {}
+    for rank in (0, 1):
+        part = {k: m for k, m in ark.read_scp(str(tmp_path / "two" / ("feats.%d.scp" % rank)))}
+        assert part and not (set(part) & set(two))
+        two.update(part)
+    assert set(one) == set(two) == {"utt%d" % i for i in range(7)}
+    for k in one:
+        # the sums are added in another order over two ranks: scale / offset agree to rounding, not to the bit
+        assert one[k].shape == two[k].shape and np.abs(one[k] - two[k]).max() < 1e-5, k
+    allf = np.concatenate(list(two.values()))
+    assert np.abs(allf.mean(0)).max() < 1e-3 and np.abs(allf.std(0) - 1).max() < 1e-3
