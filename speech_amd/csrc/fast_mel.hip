@@ -158,6 +158,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
         if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }       // column 257: the zero a padded k-loop may touch
     }
     __syncthreads();
+    if (p.ablate & 32) { if (s_pow[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
 
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
     const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
     if (KIND == SPEECH_MFCC && tid < 4 * TILEK) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
     __syncthreads();
+    if (p.ablate & 64) { if (s_mel[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
 
     if (KIND == SPEECH_MFCC)
     {
