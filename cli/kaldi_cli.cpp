@@ -19,6 +19,8 @@
 // channel, default 0); the samples go to the device as int16 (speech_extract_pcm16, include/speech_hip.h) and keep their
 // integer scale, as Kaldi's wave reader leaves them.  The sample rate comes from the header unless -r is given, and an
 // -r that contradicts the header is an error.  The output is float32.
+// --raw=<f32|f64|s16> reads the input as headerless samples of that type up to the end of the file or stream and writes
+// the features headerless too (f32 for s16 input), frame-major -- the raw tensor I/O of SURVEY.md 8(f1).
 // --wav_scp=<file> takes a Kaldi wav.scp ("<utt-id> <path to .wav>" per line; no pipes) instead of one input file and writes
 // every utterance's features into one archive (-o, with --scp the matching script file): the whole list goes through
 // speech_plan_run_host in groups, int16 over PCIe, the usage of compute-mfcc-feats scp:wav.scp ark,scp:feats.ark,feats.scp.
@@ -283,6 +285,7 @@ static void usage()
     printf(fmt, "--append", "with --ark: append to the archive instead of replacing it");
     printf(fmt, "--scp=<file>", "with --ark and -o: append \"<utt-id> <ofile>:<offset>\" to this script file");
     printf(fmt, "--channel=<n>", "with a .wav input: the channel to use [default=0]");
+    printf(fmt, "--raw=<f32|f64|s16>", "the input is headerless samples of this type; the output is headerless too");
     printf(fmt, "--wav_scp=<file>", "list of \"<utt-id> <.wav path>\" lines instead of <file>; -o is a Kaldi archive");
     printf(fmt, "-h, --help", "display this help and exit");
     cout << "\nMakes Kaldi " << (TOOL == TOOL_SPECTROGRAM ? "spectrogram" : TOOL == TOOL_FBANK ? "mel-fbank" : TOOL == TOOL_MFCC ? "MFCC" : "PLP")
@@ -299,7 +302,7 @@ int main(int argc, char *argv[])
     double sr = 16000.0, fl = 25.0, shft = 10.0, d = 0.1, p = 0.97, lof = 20.0, hif = 0.0, Q = 22.0, compress = 1.0 / 3.0, cep_scale = 1.0;
     long Bi = 23, Ci = 13, channel = 0;
     int snipe = 0, dc0 = 0, rawe = 0, amp = 0, lg = 0, usee = 0, mn0 = 0, help = 0;
-    string wintype = "povey", ofile, ark_key, scp_file, wav_scp;
+    string wintype = "povey", ofile, ark_key, scp_file, wav_scp, raw_type;
     bool have_o = false, append = false, have_r = false;
 
     static const option longopts[] = {
@@ -310,7 +313,7 @@ int main(int argc, char *argv[])
         {"B", required_argument, nullptr, 'b'}, {"log", no_argument, nullptr, 'g'}, {"C", required_argument, nullptr, 'c'}, {"Q", required_argument, nullptr, 'q'},
         {"use_energy", no_argument, nullptr, 'x'}, {"zero_mean", no_argument, nullptr, 'm'}, {"ofile", required_argument, nullptr, 'o'},
         {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001},
-        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {"wav_scp", required_argument, nullptr, 1006}, {nullptr, 0, nullptr, 0}};
+        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {"wav_scp", required_argument, nullptr, 1006}, {"raw", required_argument, nullptr, 1007}, {nullptr, 0, nullptr, 0}};
     const char *shortopts = TOOL == TOOL_SPECTROGRAM ? "r:t:s:ed:zyp:w:mo:h" : TOOL == TOOL_FBANK ? "r:t:s:ed:zyp:w:al:u:b:gxmo:h" : "r:t:s:ed:zyp:w:l:u:b:c:q:xmo:h";
     int c, nerrs = 0;
     opterr = 0;
@@ -334,6 +337,7 @@ int main(int argc, char *argv[])
             case 1003: scp_file = optarg; break;
             case 1004: append = true; break;
             case 1006: wav_scp = optarg; break;
+            case 1007: raw_type = optarg; if (raw_type != "f32" && raw_type != "f64" && raw_type != "s16") { ++nerrs; } break;
             case 1005: channel = strtol(optarg, &end, 10); if (end == optarg || *end || channel < 0) { ++nerrs; } break;
             default: ++nerrs; cerr << prog() << ": invalid option \"" << argv[optind - 1] << "\"" << endl; break;
         }
@@ -357,9 +361,25 @@ int main(int argc, char *argv[])
     NpyInfo i1;
     WavInfo wav;
     char magic[8] = {0};
-    if (!list_mode && !is.read(magic, 8)) { FAIL("problem reading header for input file"); }
-    const bool is_wav = memcmp(magic, "RIFF", 4) == 0;
+    const bool raw_mode = !raw_type.empty();
+    if (raw_mode && list_mode) { FAIL("--raw and --wav_scp exclude each other"); }
+    vector<char> rawbuf;
+    if (raw_mode) { rawbuf.assign(istreambuf_iterator<char>(is), istreambuf_iterator<char>()); }
+    else if (!list_mode && !is.read(magic, 8)) { FAIL("problem reading header for input file"); }
+    bool is_wav = memcmp(magic, "RIFF", 4) == 0;
     if (list_mode) { }
+    else if (raw_mode)
+    {
+        const size_t es = raw_type == "f64" ? 8u : (raw_type == "f32" ? 4u : 2u);
+        if (rawbuf.size() % es != 0u) { FAIL("input size is not a multiple of the sample size"); }
+        i1.f64 = raw_type == "f64"; i1.fortran = false; i1.shape.assign(1, rawbuf.size() / es); i1.n = rawbuf.size() / es;
+        if (raw_type == "s16")                                                               // the 16-bit PCM path, no header: -r gives the rate
+        {
+            is_wav = true; wav.rate = (unsigned)sr; wav.channels = 1;
+            wav.x.resize(i1.n);
+            if (i1.n) { memcpy(wav.x.data(), rawbuf.data(), rawbuf.size()); }
+        }
+    }
     else if (is_wav)
     {
         string why;
@@ -454,7 +474,7 @@ int main(int argc, char *argv[])
         ark_off += (long long)ark_key.size() + 1;                                            // the scp offset points at the "\0B"
         if (!os) { FAIL("problem writing header for output file 1"); }
     }
-    else if (wo1 && !write_npy_header(os, i1.f64, i1.fortran, i1.fortran ? D : W, i1.fortran ? W : D)) { FAIL("problem writing header for output file 1"); }
+    else if (wo1 && !raw_mode && !write_npy_header(os, i1.f64, i1.fortran, i1.fortran ? D : W, i1.fortran ? W : D)) { FAIL("problem writing header for output file 1"); }
 
     timespec tic, toc;
     clock_gettime(CLOCK_REALTIME, &tic);
@@ -470,7 +490,8 @@ int main(int argc, char *argv[])
     else if (!i1.f64)
     {
         vector<float> X(N), Y(W * D + 1);
-        if (!is.read((char *)X.data(), (streamsize)(N * sizeof(float)))) { FAIL("problem reading input file (X)"); }
+        if (raw_mode) { memcpy(X.data(), rawbuf.data(), N * sizeof(float)); }
+        else if (!is.read((char *)X.data(), (streamsize)(N * sizeof(float)))) { FAIL("problem reading input file (X)"); }
         if (TOOL == TOOL_SPECTROGRAM) { rc = codee::kaldi_spectrogram_s(Y.data(), X.data(), N, (float)sr, (float)fl, (float)shft, snipe, (float)d, dc0, rawe, (float)p, wintype.c_str(), mn0); }
         else if (TOOL == TOOL_FBANK) { rc = codee::kaldi_fbank_s(Y.data(), X.data(), N, (float)sr, (float)fl, (float)shft, snipe, (float)d, dc0, rawe, (float)p, wintype.c_str(), amp, (float)lof, (float)hif, B, lg, usee, mn0); }
         else if (TOOL == TOOL_MFCC) { rc = codee::kaldi_mfcc_s(Y.data(), X.data(), N, (float)sr, (float)fl, (float)shft, snipe, (float)d, dc0, rawe, (float)p, wintype.c_str(), (float)lof, (float)hif, B, C, (float)Q, usee, mn0); }
@@ -481,7 +502,8 @@ int main(int argc, char *argv[])
     else
     {
         vector<double> X(N), Y(W * D + 1);
-        if (!is.read((char *)X.data(), (streamsize)(N * sizeof(double)))) { FAIL("problem reading input file (X)"); }
+        if (raw_mode) { memcpy(X.data(), rawbuf.data(), N * sizeof(double)); }
+        else if (!is.read((char *)X.data(), (streamsize)(N * sizeof(double)))) { FAIL("problem reading input file (X)"); }
         if (TOOL == TOOL_SPECTROGRAM) { rc = codee::kaldi_spectrogram_d(Y.data(), X.data(), N, sr, fl, shft, snipe, d, dc0, rawe, p, wintype.c_str(), mn0); }
         else if (TOOL == TOOL_FBANK) { rc = codee::kaldi_fbank_d(Y.data(), X.data(), N, sr, fl, shft, snipe, d, dc0, rawe, p, wintype.c_str(), amp, lof, hif, B, lg, usee, mn0); }
         else if (TOOL == TOOL_MFCC) { rc = codee::kaldi_mfcc_d(Y.data(), X.data(), N, sr, fl, shft, snipe, d, dc0, rawe, p, wintype.c_str(), lof, hif, B, C, Q, usee, mn0); }

@@ -280,3 +280,46 @@ def test_wav_scp_to_archive(tmp_path):
     assert len(again) == 8 and all(np.array_equal(again[i][2], again[i + 4][2]) for i in range(4))
     by_scp = list(ark.read_scp(str(scp)))
     assert len(by_scp) == 8 and all(np.array_equal(a[1], b[2]) for a, b in zip(by_scp, again))
+
+
+def test_raw_input_validates_on_cpu(tmp_path):
+    f = tmp_path / "x.raw"
+    f.write_bytes(b"\0" * 4001)
+    r = run("kaldi_mfcc", "-d0", "--raw=f32", str(f), "-o", str(tmp_path / "y.raw"))
+    assert r.returncode == 1 and "not a multiple of the sample size" in r.stderr.decode()
+    r = run("kaldi_mfcc", "-d0", "--raw=u8", str(f), "-o", str(tmp_path / "y.raw"))
+    assert r.returncode == 1 and "invalid command line" in r.stderr.decode()
+    f.write_bytes(b"")
+    r = run("kaldi_mfcc", "-d0", "--raw=f32", str(f), "-o", str(tmp_path / "y.raw"))
+    assert r.returncode == 1 and "input (X) found to be empty" in r.stderr.decode()
+    f.write_bytes(b"\0" * 4000)
+    r = run("kaldi_fbank", "-d0", "--raw=f64", str(f), "-o", str(tmp_path / "y.raw"))
+    assert r.returncode == 1 and "input data type must be in {1}" in r.stderr.decode()
+    r = run("kaldi_mfcc", "-d0", "--raw=f32", "--wav_scp=%s" % f, "-o", str(tmp_path / "y.raw"))
+    assert r.returncode == 1 and "exclude each other" in r.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_raw_input_and_output(tmp_path):
+    """headerless samples in, headerless frame-major features out, for the three sample types; stdin to stdout too"""
+    from speech_amd import api
+    x = signals.utterance(9000, 55)
+    want = api.kaldi_mfcc(x)
+    for typ, data, dt in (("f32", x.astype(np.float32), np.float32), ("f64", x.astype(np.float64), np.float64), ("s16", x.astype(np.int16), np.float32)):
+        f = tmp_path / ("x." + typ)
+        f.write_bytes(data.tobytes())
+        r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "--raw=" + typ, str(f), "-o", str(tmp_path / "y.raw"))
+        assert r.returncode == 0, r.stderr
+        y = np.fromfile(tmp_path / "y.raw", dtype=dt).reshape(-1, 13)
+        ref = api.kaldi_mfcc(x.astype(np.float64)) if typ == "f64" else want
+        assert np.array_equal(y, ref), typ
+    r = run("kaldi_spectrogram", "-e", "-z", "-d0", "-r", "8000", "--raw=s16", "-", stdin=x.astype(np.int16).tobytes())
+    assert r.returncode == 0, r.stderr
+    s = np.frombuffer(r.stdout, dtype=np.float32).reshape(-1, 129)
+    assert np.array_equal(s, api.kaldi_spectrogram(x, sr=8000.0, raw_energy=0))
+    # raw in, archive out
+    r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "--raw=f32", "--ark=u", str(tmp_path / "x.f32"), "-o", str(tmp_path / "y.ark"))
+    assert r.returncode == 0, r.stderr
+    from speech_amd import ark
+    (k, _, m), = list(ark.read_ark(str(tmp_path / "y.ark")))
+    assert k == "u" and np.array_equal(m, want)
