@@ -162,3 +162,18 @@ def test_batch_driver_matches_single_calls():
         got = Y[int(yo[i]):int(yo[i]) + y.size].reshape(y.shape)
         assert np.array_equal(got, y)
     lib.oracle_set_fft_exact(1)
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers():
+    """oracle/san_driver.c: every extractor over the edge cases where the reference has out-of-bounds hazards (tiny frames,
+    B = 1, C = 1, one-sample signals, hif above Nyquist), outputs sized exactly W x D, built with -fsanitize=address,undefined"""
+    import os
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    subprocess.check_call(["make", "-C", odir, "san"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(odir, "_san", "oracle_san")], capture_output=True, env=env, timeout=600)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    assert "AddressSanitizer" not in err and "runtime error" not in err and "LeakSanitizer" not in err
+    assert b"0 failure(s)" in r.stdout
