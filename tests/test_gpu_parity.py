@@ -249,6 +249,51 @@ def test_packed_arrays_beyond_4_GiB(kind, nutt):
     torch.cuda.empty_cache()
 
 
+def test_full_size_config3_ragged_100k_utterances():
+    """BASELINE config 3 at full size: 80-bin log fbank over 100 000 utterances of 1-30 s (1.55 M audio-s, 99 GB of audio
+    and 50 GB of features resident in HBM, one launch of 4.8 M tiles).  Size-independent properties: the frame count, every
+    feature finite, the last-bin quirk on every frame, and 24 utterances spread over the batch equal to the bit what the
+    same audio gives as a batch of one; one of them is checked against the oracle."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 170 * 2 ** 30:
+        pytest.skip("needs 170 GB of free HBM")
+    rng = np.random.default_rng(3)
+    lens = rng.integers(16000, 480001, size=100000)
+    lens[:3] = (16000, 480000, 16001)
+    plan = api.Plan("fbank", B=80)
+    b = api.Batch(plan, lens)
+    assert b.total_frames == int((1 + (lens - 400) // 160).sum()) and b.total_samples == int(lens.sum())
+    torch.manual_seed(33)
+    X = torch.empty(b.total_samples, device="cuda")
+    step = 1 << 30
+    for i in range(0, b.total_samples, step):                              # int16-scale noise, whole numbers
+        X[i:i + step].normal_(0.0, 3000.0).round_()
+    Y = torch.empty(b.total_out, device="cuda")
+    b.run(X, Y)
+    torch.cuda.synchronize()
+    Yv = Y.view(-1, 80)
+    for i in range(0, Yv.shape[0], 1 << 24):
+        blk = Yv[i:i + (1 << 24)]
+        assert bool(torch.isfinite(blk).all()) and bool((blk[:, 79] == blk[:, 78]).all())
+    picks = [0, 1, 2, 99999, int(np.argmin(lens)), int(np.argmax(lens))] + [int(u) for u in rng.integers(0, 100000, size=18)]
+    for u in picks:
+        n, xo, yo, W = int(lens[u]), int(b.x_off[u]), int(b.y_off[u]), int(b.n_frames[u])
+        b1 = api.Batch(plan, [n])
+        y1 = torch.empty(b1.total_out, device="cuda")
+        b1.run(X[xo:xo + n], y1)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, Y[yo:yo + W * 80]), u
+        b1.close()
+    u = 0
+    ok, msg = _parity("fbank", dict(B=80), X[int(b.x_off[u]):int(b.x_off[u]) + int(lens[u])].cpu().numpy(),
+                      Y[int(b.y_off[u]):int(b.y_off[u]) + int(b.n_frames[u]) * 80].cpu().numpy().reshape(-1, 80))
+    assert ok, msg
+    b.close(); plan.close()
+    del X, Y, Yv
+    torch.cuda.empty_cache()
+
+
 def test_one_hour_utterance_through_the_dropin_entry():
     """one utterance of 57.6 M samples (1 h at 16 kHz, 230 MB) through kaldi_mfcc_s with host pointers: 359 998 frames.
     The audio is a 10 s signal repeated, and 10 s is a whole number of frame shifts, so frames 1000 k .. 1000 k + 997
