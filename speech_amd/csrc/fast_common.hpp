@@ -35,7 +35,7 @@ namespace speech {
 
 constexpr int MAX_MTILES = 8;            // mel tiles of up to 16 columns (B <= 128), balanced over the waves; cepstral tiles of 16 (C <= 96)
 
-struct FastGeom { bool ok, pair; int fw, nz, tile; size_t span, ws, lds; };      // launch geometry of a plan, fast_geom()
+struct FastGeom { bool ok, pair, wide; int fw, nz, tile; size_t span, ws, lds; };      // launch geometry of a plan, fast_geom()
 
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[8][16] complex
@@ -66,6 +66,9 @@ constexpr int TR_WAVE = 1032;           // floats of a wave's LDS slice: 4 frame
                                         // imaginary parts), 4 x 257 outputs; four slices = the 16 x 258 power tile
 constexpr int PP2 = 130;                // pitch of the 64 x 129 power tile of the pair mode (also = 2 mod 32)
 constexpr int PP = 258;                 // pitch of the TILE x 257 power tile (= 2 mod 32: conflict-free MFMA operand reads)
+// 1024-point plans ("wide": one frame on 32 lanes, frame_power_wide): win[1024] | tw1 | tw2 | tw3[8][16] complex = W1024^(k2 + 16 k1)
+constexpr int TABW_WIN = 0, TABW_TW1 = 1024, TABW_TW2 = 1536, TABW_TW3 = 1792, TABW_FLOATS = 2048;
+constexpr int PPW = 514;                // pitch of the 16 x 513 power tile of the wide mode (= 2 mod 32)
 constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
 struct FastParams {
@@ -94,7 +97,7 @@ struct FastParams {
 typedef void (*kernel_fn)(const FastParams);
 // the instantiation that serves a plan: nz = rows of samples that hold data (9..16), pair = two frames per transform
 kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair);      // fast_spectrogram.hip
-kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair);              // fast_mel.hip
+kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide);   // fast_mel.hip
 
 namespace {
 
@@ -296,12 +299,12 @@ __device__ __forceinline__ void store_run(float *y, const float *s_src, int nout
 // 256-point complex FFT of z[n], n = n1 + 16 n2, lane n1 holding z[n1 + 16 n2] in z[n2]: 16-point FFT over n2 in registers,
 // twiddle W256^(n1 k2), transposition through the wave's LDS slice, 16-point FFT over n1.  On return lane k2 (= n1) holds
 // Z[k2 + 16 k1] at position P16(k1).
-template <bool HALF>
+template <bool HALF, int TW1 = TAB_TW1>
 __device__ __forceinline__ void fft256(f2 (&z)[16], const float *s_tab, float *s_tr, const int lane)
 {
     const int f = lane >> 4, n1 = lane & 15;
     fft16(z);
-    const f2 *tw1 = reinterpret_cast<const f2 *>(s_tab + TAB_TW1);
+    const f2 *tw1 = reinterpret_cast<const f2 *>(s_tab + TW1);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) { z[P16(k2)] = cmul(z[P16(k2)], tw1[k2 * 16 + n1]); }
     wave_sync();                                                            // every lane has its samples: the slice becomes the transposition image
@@ -477,6 +480,135 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
         const f2 t = cmul(mi_sub_conj(zk, zp), tw2[k1 * 16 + k2]);          // 2O exp(-i pi k / 256), 2O = -i (Z[k] - conj Z[256-k])
         const f2 a = e + t, b = e - t;
         const f2 qa = a * a, qb = b * b;
+        pa[k1] = qa.x + qa.y;
+        pb[k1] = qb.x + qb.y;
+    }
+}
+
+// 1024-point plans: ONE real frame of 513 .. 1024 samples on 32 lanes.  Its even samples xe[m] = x[2m] and its odd samples
+// xo[m] = x[2m+1] are two real sequences of 512 points: lanes 16 g .. 16 g + 15 with g even take the even ones, g odd the odd
+// ones, each exactly as frame_power treats a 512-point frame (packing, 256-point complex FFT, untangle -- but keeping the
+// complex bins), and
+//   X[k] = E[k] + W1024^k O[k],     X[512-k] = conj(E[k] - W1024^k O[k]),     k = 0 .. 256
+// joins the halves after ONE exchange between lanes l and l ^ 16: the untangle leaves a = 2 S[k] and b = 2 conj S[256-k]
+// (S = E or O) in every lane; the even group computes bins k and 512-k from (aE, aO), the odd group bins 256-k and 256+k
+// from (bE, bO) with conj W1024^(256-k) = i W1024^k.
+// NZ = ceil(L / 64) rows of 64 samples hold data; fa = the frame's first sample in the slice.  With k = k2 + 16 k1, k1 < 8:
+//   even-group lanes: pa[k1] = 4 |X[k]|^2,     pb[k1] = 4 |X[512-k]|^2;  lane k2 = 0 also pa[8], pb[8] = bins 128, 384
+//   odd-group lanes:  pa[k1] = 4 |X[256-k]|^2, pb[k1] = 4 |X[256+k]|^2
+template <int NZ>
+__device__ __forceinline__ void frame_power_wide(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
+                                                 float (&pa)[9], float (&pb)[9], float &rawe)
+{
+    const int n1 = lane & 15, h = (lane >> 4) & 1;
+    const int L = p.L;
+    const int i00 = 4 * n1 + h;                                             // the lane's samples of row n2: i00 + 64 n2 and that + 2
+    const int ilast = i00 + 64 * (NZ - 1);
+    const bool v0 = ilast < L, v1 = ilast + 2 < L;
+    const float *win = s_tab + TABW_WIN;
+    f2 z[16];
+    float sum = 0.0f;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2)
+    {
+        if (n2 < NZ)
+        {
+            f2 v = {fa[i00 + 64 * n2], fa[i00 + 64 * n2 + 2]};
+            if (n2 == NZ - 1) { v.x = v0 ? v.x : 0.0f; v.y = v1 ? v.y : 0.0f; }
+            z[n2] = v;
+            sum += v.x + v.y;
+        }
+        else { z[n2] = f2{0.0f, 0.0f}; }
+    }
+    float mean = 0.0f;
+    if (p.dc0)                                                              // c/kaldi_mfcc.c:265-271
+    {
+        float tot = row16_sum(sum);
+        tot += __shfl_xor(tot, 16, 64);
+        mean = tot / (float)L;
+    }
+    const float npre = -p.preemph;
+    float e = 0.0f;
+#pragma unroll
+    for (int n2 = 0; n2 < NZ; ++n2)
+    {
+        z[n2] -= f2{mean, mean};
+        if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
+    }
+    if (p.want_pre)                                                         // c/kaldi_mfcc.c:274-279
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < NZ; ++n2)
+    {
+        // pre-emphasis y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0] (c/kaldi_mfcc.c:282-288), window (:291)
+        const int i0 = i00 + 64 * n2;
+        const float xp0 = fa[(i0 > 0) ? i0 - 1 : 0] - mean, xp1 = fa[i0 + 1] - mean;
+        f2 y;
+        y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
+        y.y = fmaf(npre, xp1, z[n2].y) * win[i0 + 2];
+        if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
+        z[n2] = y;
+    }
+    if (p.want_post)                                                        // c/kaldi_mfcc.c:295-301
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+    }
+    {
+        float tot = row16_sum(e);
+        tot += __shfl_xor(tot, 16, 64);
+        rawe = fmaxf(tot, FLT_EPSILON);
+    }
+
+    fft256<true, TABW_TW1>(z, s_tab, s_tr, lane);
+    const int k2 = n1;
+
+    // untangle within the 16-lane group (as frame_power), keeping a = 2 S[k] and b = 2 conj S[256-k]; then the exchange
+    const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
+    const int xaddr = (lane ^ 16) << 2;
+    const bool lane0 = (k2 == 0);
+    const f2 *tw2 = reinterpret_cast<const f2 *>(s_tab + TABW_TW2);
+    const f2 *tw3 = reinterpret_cast<const f2 *>(s_tab + TABW_TW3);
+    {
+        // bin 128 of the halves (lane 0): S[128] = conj Z[128]; X[128], X[384] = E[128] +- exp(-i pi / 4) O[128]
+        const f2 z8 = z[P16(8)];
+        const f2 a8 = {2.0f * z8.x, -2.0f * z8.y};
+        f2 o8;
+        o8.x = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(a8.x)));
+        o8.y = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(a8.y)));
+        const f2 w = {0.70710678118654752440f, -0.70710678118654752440f};
+        const f2 t = cmul(o8, w);
+        const f2 xa = a8 + t, xb = a8 - t;
+        const f2 qa = xa * xa, qb = xb * xb;
+        pa[8] = qa.x + qa.y;
+        pb[8] = qb.x + qb.y;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+    {
+        const f2 zo = z[P16((15 - k1) & 15)], zs = z[P16((16 - k1) & 15)];
+        f2 zp;
+        zp.x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.x)));
+        zp.y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.y)));
+        zp.x = lane0 ? zs.x : zp.x;
+        zp.y = lane0 ? zs.y : zp.y;
+        const f2 zk = z[P16(k1)];
+        const f2 ee = add_conj(zk, zp);
+        const f2 tt = cmul(mi_sub_conj(zk, zp), tw2[k1 * 16 + k2]);
+        const f2 a = ee + tt, b = ee - tt;                                  // 2 S[k], 2 conj S[256-k]
+        const f2 send = h ? a : b;
+        f2 recv;
+        recv.x = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(send.x)));
+        recv.y = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(send.y)));
+        const f2 w = tw3[k1 * 16 + k2];
+        const f2 u = h ? recv : a, v = h ? b : recv;
+        const f2 g = h ? f2{-w.y, w.x} : w;                                 // odd group: conj W1024^(256-k) = i W1024^k
+        const f2 t = cmul(v, g);
+        const f2 xa = u + t, xb = u - t;
+        const f2 qa = xa * xa, qb = xb * xb;
         pa[k1] = qa.x + qa.y;
         pb[k1] = qb.x + qb.y;
     }

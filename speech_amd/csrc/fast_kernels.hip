@@ -16,13 +16,17 @@ static int mel_pitch(int cols) { return 32 * ((cols + 31) / 32) + 2; }          
 static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
 {
     FastGeom g; memset(&g, 0, sizeof(g));
-    if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u)) { return g; }
+    if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u && nfft != 2u * (size_t)NFFT)) { return g; }
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return g; }
     g.pair = (nfft == (size_t)NFFT / 2u);
-    g.fw = g.pair ? 2 * QF : QF;
-    g.nz = g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u);
-    const size_t F = nfft / 2u + 1u, rows = g.pair ? 16u * (size_t)g.nz : 32u * (size_t)g.nz;
+    g.wide = (nfft == 2u * (size_t)NFFT);
+    // 1024-point frames: the mel kinds only, and without dither (both fall to the generic kernels)
+    if (g.wide && (o.kind == SPEECH_SPECTROGRAM || (float)o.dither > FLT_EPSILON)) { return g; }
+    g.fw = g.wide ? 2 : (g.pair ? 2 * QF : QF);
+    g.nz = g.wide ? (int)((L + 63u) / 64u) : (g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u));
+    const size_t F = nfft / 2u + 1u, rows = (g.wide ? 64u : (g.pair ? 16u : 32u)) * (size_t)g.nz;
+    const size_t tabf = g.wide ? (size_t)TABW_FLOATS : (size_t)TAB_FLOATS;
     g.span = (((size_t)g.fw - 1u) * stp + rows + 63u) & ~(size_t)63;        // whole 64-lane load instructions fit the slice
     if (o.kind == SPEECH_SPECTROGRAM)
     {
@@ -43,12 +47,12 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     }
     g.tile = MW * g.fw;
     const size_t T = (size_t)g.tile;
-    g.ws = std::max(g.span, g.pair ? (T * PP2 + MW - 1) / MW : (size_t)TR_WAVE);     // the slices together hold the power tile
+    g.ws = std::max(g.span, g.wide ? (T * PPW + MW - 1) / MW : (g.pair ? (T * PP2 + MW - 1) / MW : (size_t)TR_WAVE));     // the slices together hold the power tile
     // behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile; the mfcc / plp output and
     // autocorrelation tiles reuse the power tile's place
     const size_t extra = T + (o.kind == SPEECH_FBANK ? ((T * D + 3u) & ~(size_t)3) : T * (size_t)mel_pitch((int)cols));
     if (((T * D + 3u) & ~(size_t)3) + T * 17u > (size_t)MW * g.ws) { return g; }
-    g.lds = (TAB_FLOATS + MW * g.ws + extra) * sizeof(float);
+    g.lds = (tabf + MW * g.ws + extra) * sizeof(float);
     g.ok = g.lds <= 64u * 1024u;
     return g;
 }
@@ -79,7 +83,7 @@ static hipError_t opt_in_lds(kernel_fn k)
 static kernel_fn plan_kernel(const FastTables *t, bool dither, bool pcm)
 {
     if (t->kind == SPEECH_SPECTROGRAM) { return fast_spectrogram_kernel_for(t->nz, dither, pcm, t->geom.pair); }
-    return fast_mel_kernel_for(t->nz, t->kind, dither, t->geom.pair);
+    return fast_mel_kernel_for(t->nz, t->kind, dither, t->geom.pair, t->geom.wide);
 }
 
 static hipError_t upload_floats(const std::vector<float> &h, float **d)
@@ -98,18 +102,25 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
                                const std::vector<float> &lift, const std::vector<float> &eql, const std::vector<float> &idft, std::string *err)
 {
     if (err) { err->clear(); }
-    std::vector<float> tab(TAB_FLOATS, 0.0f);
     const FastGeom g = fast_geom(o, L, nfft);
     if (!g.ok) { return nullptr; }
+    std::vector<float> tab(g.wide ? TABW_FLOATS : TAB_FLOATS, 0.0f);
+    const int o_win = g.wide ? TABW_WIN : TAB_WIN, o_tw1 = g.wide ? TABW_TW1 : TAB_TW1, o_tw2 = g.wide ? TABW_TW2 : TAB_TW2;
     if (g.pair) { for (size_t l = 0; l < L; ++l) { tab[TAB_WIN + 2 * l] = win[l]; tab[TAB_WIN + 2 * l + 1] = win[l]; } }      // (w, w): one factor for frame A and B
-    else { for (size_t l = 0; l < L && l < (size_t)NFFT; ++l) { tab[TAB_WIN + l] = win[l]; } }
+    else { for (size_t l = 0; l < L && l < nfft; ++l) { tab[o_win + l] = win[l]; } }
     const long double pi = 3.141592653589793238462643383279502884L;
     for (int k2 = 0; k2 < 16; ++k2) { for (int n1 = 0; n1 < 16; ++n1) {
         const long double a = -2.0L * pi * (long double)(n1 * k2) / (long double)NC;
-        tab[TAB_TW1 + (k2 * 16 + n1) * 2] = (float)cosl(a); tab[TAB_TW1 + (k2 * 16 + n1) * 2 + 1] = (float)sinl(a); } }
+        tab[o_tw1 + (k2 * 16 + n1) * 2] = (float)cosl(a); tab[o_tw1 + (k2 * 16 + n1) * 2 + 1] = (float)sinl(a); } }
     for (int k1 = 0; k1 < 8; ++k1) { for (int k2 = 0; k2 < 16; ++k2) {
         const long double a = -pi * (long double)(k2 + 16 * k1) / (long double)NC;
-        tab[TAB_TW2 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[TAB_TW2 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
+        tab[o_tw2 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[o_tw2 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
+    if (g.wide)
+    {
+        for (int k1 = 0; k1 < 8; ++k1) { for (int k2 = 0; k2 < 16; ++k2) {
+            const long double a = -2.0L * pi * (long double)(k2 + 16 * k1) / 1024.0L;
+            tab[TABW_TW3 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[TABW_TW3 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
+    }
     FastTables *t = new (std::nothrow) FastTables();
     if (!t) { if (err) { *err = "out of host memory"; } return nullptr; }
     t->d_tab = t->d_melw = t->d_mat2 = t->d_aux = nullptr;
@@ -117,7 +128,7 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     t->B = t->C = t->P = t->MP = t->Cp = t->K2 = t->ntile_m = t->ntile_c = 0;
     t->F = (int)(nfft / 2u + 1u);
     t->D = t->F;
-    const int klim = g.pair ? PP2 : PP;                                      // power-tile columns a k-loop may touch
+    const int klim = g.wide ? PPW : (g.pair ? PP2 : PP);                      // power-tile columns a k-loop may touch
     std::vector<float> melw, mat2, aux;
     if (o.kind != SPEECH_SPECTROGRAM)
     {

@@ -57,28 +57,32 @@ __device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const __amdgpu_bu
 // Levinson-Durbin and the cepstral recursion stay in registers).
 // PAIR (256-point plans): 8 frames per wave as 4 pairs (frame_power_pair), 64 frames per tile, a 64 x 130
 // power tile; NZ then counts rows of 16 samples.
-template <int NZ, int KIND, int P, bool DITHER, bool PAIR>
+// WIDE (1024-point plans): 2 frames per wave, 32 lanes each (frame_power_wide), 16 frames per tile, a 16 x 514 power
+// tile; NZ counts rows of 64 samples.
+template <int NZ, int KIND, int P, bool DITHER, bool PAIR, bool WIDE = false>
 __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
 {
-    constexpr int FWK = PAIR ? 2 * QF : QF;                                 // frames per wave
+    static_assert(!(PAIR && WIDE) && !(WIDE && DITHER), "one mode at a time; the wide mode has no dithered form");
+    constexpr int FWK = WIDE ? 2 : (PAIR ? 2 * QF : QF);                    // frames per wave
     constexpr int TILEK = MW * FWK;                                         // frames per workgroup
     constexpr int RTK = TILEK / 16;                                         // 16-frame row tiles
-    constexpr int PPK = PAIR ? PP2 : PP;                                     // pitch of the power tile
+    constexpr int PPK = WIDE ? PPW : (PAIR ? PP2 : PP);                     // pitch of the power tile
+    constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;                   // floats of tables in front of the slices
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
-    float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image
+    float *s_aud = smem + TABK + wv * p.ws;                                 // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
     // after the FFTs the slices are dead and hold the TILEK x PPK power tile
-    float *s_pow = smem + TAB_FLOATS;
+    float *s_pow = smem + TABK;
     // private region behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile.  The mfcc / plp output
     // tile (and plp's autocorrelations) are written after the power tile is dead and reuse its place.
-    float *s_e = smem + TAB_FLOATS + MW * p.ws;
+    float *s_e = smem + TABK + MW * p.ws;
     float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILEK : s_pow;
     float *s_mel = s_e + TILEK;
     float *s_ac = s_out + ((TILEK * p.D + 3) & ~3);
-    for (int i = tid; i < TAB_FLOATS; i += NTM) { s_tab[i] = p.tab[i]; }
+    for (int i = tid; i < TABK; i += NTM) { s_tab[i] = p.tab[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
@@ -95,7 +99,12 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     const int f = lane >> 4, k2 = lane & 15;
     float pa[9], pb[9], rawe = 1.0f;
     f2 rawe2 = {1.0f, 1.0f};
-    if (nfr > 0 && PAIR)
+    if (nfr > 0 && WIDE)
+    {
+        // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds; its row is never stored)
+        frame_power_wide<NZ>(s_aud + (lane >> 5) * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
+    }
+    else if (nfr > 0 && PAIR)
     {
         // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its row is never stored)
         const unsigned long long ku = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.uid << 32)) : 0ull;
@@ -120,7 +129,27 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (p.ablate & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILEK x 257 tile, column 257 zero
-    if (PAIR)
+    if (WIDE)
+    {
+        // even-group lanes hold bins k and 512 - k, odd-group lanes 256 - k and 256 + k (k = k2 + 16 k1); column 513 is the zero
+        // a padded k-loop may touch
+        float *pr = s_pow + (fq + (lane >> 5)) * PPK;
+        const int hh = (lane >> 4) & 1;
+        if (p.amp)
+        {
+#pragma unroll
+            for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+        {
+            const int k = k2 + 16 * k1;
+            pr[hh ? 256 - k : k] = pa[k1];
+            pr[hh ? 256 + k : 512 - k] = pb[k1];
+        }
+        if (k2 == 0 && hh == 0) { pr[128] = pa[8]; pr[384] = pb[8]; pr[513] = 0.0f; s_e[fq + (lane >> 5)] = rawe; }
+    }
+    else if (PAIR)
     {
         // pa[k1] / pb[k1]: bin k2 + 16 k1 of frames A / B, 129 bins each; column 129 is the zero a padded k-loop may touch
         float *pra = s_pow + (fq + 2 * f) * PPK, *prb = pra + PPK;
@@ -287,14 +316,29 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     for (int i = tid; i < nout; i += NTM) { y[i] = s_out[i]; }
 }
 
-template <int NZ, bool DITHER, bool PAIR>
+template <int NZ, bool DITHER, bool PAIR, bool WIDE = false>
 kernel_fn mel_for_kind(int kind)
 {
     switch (kind)
     {
-        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER, PAIR>;
-        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER, PAIR>;
-        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER, PAIR>;
+        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER, PAIR, WIDE>;
+        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER, PAIR, WIDE>;
+        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER, PAIR, WIDE>;
+    }
+}
+
+kernel_fn mel_wide_for_nz(int nz, int kind)
+{
+    switch (nz)
+    {
+        case 9: return mel_for_kind<9, false, false, true>(kind);
+        case 10: return mel_for_kind<10, false, false, true>(kind);
+        case 11: return mel_for_kind<11, false, false, true>(kind);
+        case 12: return mel_for_kind<12, false, false, true>(kind);
+        case 13: return mel_for_kind<13, false, false, true>(kind);
+        case 14: return mel_for_kind<14, false, false, true>(kind);
+        case 15: return mel_for_kind<15, false, false, true>(kind);
+        default: return mel_for_kind<16, false, false, true>(kind);
     }
 }
 
@@ -318,8 +362,9 @@ kernel_fn mel_for_nz(int nz, int kind, bool dither)
 
 }  // namespace
 
-kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair)
+kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide)
 {
+    if (wide) { return mel_wide_for_nz(nz, kind); }
     return pair ? mel_for_nz<true>(nz, kind, dither) : mel_for_nz<false>(nz, kind, dither);
 }
 

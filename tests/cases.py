@@ -66,6 +66,14 @@ _add("fbank", 3000, 601, sr=8000.0, hif=3800.0, B=23, snip=0)
 _add("spectrogram", 6000, 602, sr=22050.0)                       # L=551 -> nfft 1024 (sizes truncate in float)
 _add("mfcc", 12000, 603, sr=44100.0, hif=20000.0, B=40, C=20)    # L=1102 -> nfft 2048
 _add("fbank", 9000, 604, sr=32000.0, hif=16000.0, B=64, snip=0)  # L=800 -> nfft 1024
+# 1024-point frames on the tuned kernels (one frame per 32 lanes): every switch, short signals with reflected edges
+for i, (kind, extra) in enumerate((("fbank", dict(B=80)), ("fbank", dict(B=40, amp=1, use_energy=1)), ("mfcc", dict(B=23, C=13)),
+                                   ("mfcc", dict(B=40, C=40, use_energy=1)), ("plp", dict(B=23, C=13)), ("plp", dict(B=23, C=13, compress=0.5)))):
+    for j, (sr, snip, dc0, rawe) in enumerate(((22050.0, 1, 1, 1), (32000.0, 0, 0, 0), (24000.0, 0, 1, 0), (22050.0, 1, 0, 1))):
+        _add(kind, [9000, 3000, 700, 12001][j], 620 + 4 * i + j, sr=sr, hif=sr / 2, snip=snip, dc0=dc0, raw_energy=rawe,
+             win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j], **extra)
+_add("mfcc", 1024, 650, sr=16000.0, fl=64.0, fs=16.0)            # L=1024 == nfft, one frame
+_add("fbank", 3000, 651, sr=16000.0, fl=32.0625, fs=10.0, B=23)   # L=513: the shortest 1024-point frame
 _add("mfcc", 3000, 605, sr=16000.0, fl=10.0, fs=5.0)             # L=160 -> nfft 256
 _add("spectrogram", 3000, 606, sr=16000.0, fl=32.0, fs=16.0)     # L=512 == nfft
 _add("fbank", 30000, 607, sr=48000.0, fl=100.0, fs=40.0, hif=24000.0, B=80)   # L=4800 -> nfft 8192 (generic kernel)

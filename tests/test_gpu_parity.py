@@ -165,7 +165,9 @@ def test_tuned_and_generic_kernels_agree():
     import torch
     for kind, o in [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", {}), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {}),
                     ("spectrogram", dict(sr=8000.0)), ("mfcc", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(sr=8000.0, hif=4000.0, B=40, snip=0)),
-                    ("plp", dict(sr=8000.0, hif=4000.0)), ("fbank", dict(B=128, use_energy=1)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100, snip=0))]:
+                    ("plp", dict(sr=8000.0, hif=4000.0)), ("fbank", dict(B=128, use_energy=1)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100, snip=0)),
+                    ("fbank", dict(sr=22050.0, hif=11025.0, B=80)), ("mfcc", dict(sr=32000.0, hif=15000.0, snip=0)), ("plp", dict(sr=24000.0, hif=12000.0)),
+                    ("mfcc", dict(fl=64.0, fs=16.0, B=40, C=40, hif=7600.0)), ("fbank", dict(sr=22050.0, hif=11025.0, fl=46.44, fs=11.61, B=80, win="hann", preemph=0.0, dc0=0, snip=0))]:
         x = signals.utterance(24000, 77, sr=o.get("sr", 16000.0))
         X = torch.from_numpy(x).cuda()
         outs = []
@@ -467,8 +469,10 @@ def test_which_plans_run_on_the_tuned_kernels():
     tuned = [("mfcc", {}), ("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(B=40, C=40, hif=7600.0)), ("plp", {}),
              ("fbank", dict(fl=20.0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("fbank", dict(B=23, hif=9000.0)), ("mfcc", dict(dither=0.5)),
              ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("spectrogram", dict(sr=8000.0)), ("plp", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(fl=10.0, fs=5.0, B=40)),
-             ("fbank", dict(B=128)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100))]
+             ("fbank", dict(B=128)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100)),
+             ("fbank", dict(sr=22050.0, hif=11025.0, B=80)), ("mfcc", dict(sr=32000.0, hif=16000.0)), ("plp", dict(sr=24000.0, hif=12000.0)), ("mfcc", dict(fl=64.0, fs=20.0))]
     generic = [("mfcc", dict(sr=4000.0, hif=2000.0, B=15)), ("spectrogram", dict(sr=22050.0)), ("mfcc", dict(sr=16100.0)),
+               ("mfcc", dict(sr=22050.0, hif=11025.0, dither=1.0)), ("fbank", dict(sr=44100.0, hif=22050.0)),
                ("plp", dict(order=16)), ("fbank", dict(B=129)), ("mfcc", dict(fs=10.0625)), ("fbank", dict(B=1))]
     for kind, o in tuned:
         assert api.Plan(kind, **o).tuned, (kind, o)
@@ -478,7 +482,8 @@ def test_which_plans_run_on_the_tuned_kernels():
 
 
 @pytest.mark.parametrize("kind,o,dtype,pcm", [("mfcc", {}, "f32", False), ("spectrogram", dict(snip=0), "f32", False), ("fbank", dict(B=40, dither=1.0), "f32", False),
-                                               ("mfcc", dict(mn0=1, snip=0), "f64", False), ("plp", {}, "f32", True), ("fbank", dict(sr=8000.0, hif=4000.0, dither=0.5), "f64", True)])
+                                               ("mfcc", dict(mn0=1, snip=0), "f64", False), ("plp", {}, "f32", True), ("fbank", dict(sr=8000.0, hif=4000.0, dither=0.5), "f64", True),
+                                               ("fbank", dict(sr=22050.0, hif=11025.0, B=80, snip=0), "f32", True)])
 def test_run_host_equals_the_resident_batch(kind, o, dtype, pcm):
     """speech_plan_run_host: host pointers in and out, chunked over two streams -- the features of the whole list as one
     resident batch, bit for bit (dither included: the chunks carry the utterances' numbers), for any chunk size"""
@@ -549,7 +554,8 @@ def test_extract_pcm16_equals_the_drop_in_call(dtype):
 
 
 @pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(snip=0)), ("plp", {}),
-                                    ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("fbank", dict(B=40, snip=0, force_generic=1))])
+                                    ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("fbank", dict(B=40, snip=0, force_generic=1)),
+                                    ("mfcc", dict(sr=22050.0, hif=11025.0, snip=0))])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_pcm16_input_equals_float_input(kind, o, dtype):
     """speech_batch_run_pcm16: int16 audio converted on load gives bit-identical features to the float path on the same
