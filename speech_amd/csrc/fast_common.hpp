@@ -96,7 +96,7 @@ struct FastParams {
 
 typedef void (*kernel_fn)(const FastParams);
 // the instantiation that serves a plan: nz = rows of samples that hold data (9..16), pair = two frames per transform
-kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair);      // fast_spectrogram.hip
+kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide);   // fast_spectrogram.hip
 kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide);   // fast_mel.hip
 
 namespace {
@@ -496,7 +496,7 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
 // NZ = ceil(L / 64) rows of 64 samples hold data; fa = the frame's first sample in the slice.  With k = k2 + 16 k1, k1 < 8:
 //   even-group lanes: pa[k1] = 4 |X[k]|^2,     pb[k1] = 4 |X[512-k]|^2;  lane k2 = 0 also pa[8], pb[8] = bins 128, 384
 //   odd-group lanes:  pa[k1] = 4 |X[256-k]|^2, pb[k1] = 4 |X[256+k]|^2
-template <int NZ>
+template <int NZ, bool HALF>
 __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
                                                  float (&pa)[9], float (&pb)[9], float &rawe)
 {
@@ -563,7 +563,7 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
         rawe = fmaxf(tot, FLT_EPSILON);
     }
 
-    fft256<true, TABW_TW1>(z, s_tab, s_tr, lane);
+    fft256<HALF, TABW_TW1>(z, s_tab, s_tr, lane);
     const int k2 = n1;
 
     // untangle within the 16-lane group (as frame_power), keeping a = 2 S[k] and b = 2 conj S[256-k]; then the exchange

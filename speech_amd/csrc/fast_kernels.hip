@@ -21,8 +21,8 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return g; }
     g.pair = (nfft == (size_t)NFFT / 2u);
     g.wide = (nfft == 2u * (size_t)NFFT);
-    // 1024-point frames: the mel kinds only, and without dither (both fall to the generic kernels)
-    if (g.wide && (o.kind == SPEECH_SPECTROGRAM || (float)o.dither > FLT_EPSILON)) { return g; }
+    // 1024-point frames: without dither (dithered ones fall to the generic kernels)
+    if (g.wide && (float)o.dither > FLT_EPSILON) { return g; }
     g.fw = g.wide ? 2 : (g.pair ? 2 * QF : QF);
     g.nz = g.wide ? (int)((L + 63u) / 64u) : (g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u));
     const size_t F = nfft / 2u + 1u, rows = (g.wide ? 64u : (g.pair ? 16u : 32u)) * (size_t)g.nz;
@@ -30,9 +30,9 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     g.span = (((size_t)g.fw - 1u) * stp + rows + 63u) & ~(size_t)63;        // whole 64-lane load instructions fit the slice
     if (o.kind == SPEECH_SPECTROGRAM)
     {
-        g.ws = std::max(g.span + (size_t)g.fw * F, (size_t)TR_WAVE_C);      // + the wave's output, staged behind the parked audio
+        g.ws = (std::max(g.span + (size_t)g.fw * F, (size_t)TR_WAVE_C) + 3u) & ~(size_t)3;      // + the wave's output, staged behind the parked audio; slices stay 16-byte aligned
         g.tile = (NT / 64) * g.fw * 4;                                      // four sub-tiles
-        g.lds = (TAB_FLOATS + (NT / 64) * g.ws) * sizeof(float);
+        g.lds = (tabf + (NT / 64) * g.ws) * sizeof(float);
         g.ok = g.lds <= 64u * 1024u;
         return g;
     }
@@ -82,7 +82,7 @@ static hipError_t opt_in_lds(kernel_fn k)
 
 static kernel_fn plan_kernel(const FastTables *t, bool dither, bool pcm)
 {
-    if (t->kind == SPEECH_SPECTROGRAM) { return fast_spectrogram_kernel_for(t->nz, dither, pcm, t->geom.pair); }
+    if (t->kind == SPEECH_SPECTROGRAM) { return fast_spectrogram_kernel_for(t->nz, dither, pcm, t->geom.pair, t->geom.wide); }
     return fast_mel_kernel_for(t->nz, t->kind, dither, t->geom.pair, t->geom.wide);
 }
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (nfr > 0 && WIDE)
     {
         // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds; its row is never stored)
-        frame_power_wide<NZ>(s_aud + (lane >> 5) * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
+        frame_power_wide<NZ, true>(s_aud + (lane >> 5) * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
     }
     else if (nfr > 0 && PAIR)
     {

@@ -6,23 +6,27 @@ namespace {
 
 // PAIR (256-point plans): a wave carries 8 frames as 4 pairs (frame_power_pair), a sub-tile is 32 frames, a
 // tile 128; NZ then counts rows of 16 samples.
-template <int NZ, bool DITHER, bool PCM, bool PAIR>
+// WIDE (1024-point plans): 2 frames per wave, 32 lanes each (frame_power_wide), a sub-tile is 8 frames, a tile 32;
+// NZ counts rows of 64 samples.
+template <int NZ, bool DITHER, bool PCM, bool PAIR, bool WIDE = false>
 __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
 {
+    static_assert(!(PAIR && WIDE) && !(WIDE && DITHER), "one mode at a time; the wide mode has no dithered form");
+    constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
-    float *s_aud = smem + TAB_FLOATS + wv * p.ws;                           // the wave's slice: audio, then transposition image
+    float *s_aud = smem + TABK + wv * p.ws;                                 // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
-    for (int i = tid; i < TAB_FLOATS; i += NT) { s_tab[i] = p.tab[i]; }
+    for (int i = tid; i < TABK; i += NT) { s_tab[i] = p.tab[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
     const float *xu = p.X + ((p.ablate & 16) ? 0 : utt.x_off);
     const short *xu16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
-    constexpr int FW = PAIR ? 2 * QF : QF;                                  // frames per wave
+    constexpr int FW = WIDE ? 2 : (PAIR ? 2 * QF : QF);                     // frames per wave
     constexpr int SUBF = (NT / 64) * FW;                                    // frames per sub-tile
     const int nsub = ((int)tile.nframes + SUBF - 1) / SUBF;
     const unsigned long long dkey_utt = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.uid << 32)) : 0ull;
@@ -43,7 +47,12 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         f2 rawe2 = {1.0f, 1.0f};
         if (nfr > 0)
         {
-            if (PAIR)
+            if (WIDE)
+            {
+                // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds and is dropped)
+                frame_power_wide<NZ, false>(s_aud + (lane >> 5) * p.stp, s_tab + opaque_zero(), s_tr, lane, p, pa, pb, rawe);
+            }
+            else if (PAIR)
             {
                 // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its outputs are dropped)
                 const unsigned long long wa = (unsigned long long)((long long)tile.frame0 + fq + 2 * f);
@@ -71,7 +80,24 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             // requests in flight, and dword stores of 64-byte runs need eight times as many for the same bytes.
             const int D = p.D;
             float *st = s_aud + p.span + f * D;
-            if (PAIR)
+            if (WIDE)
+            {
+                // even-group lanes hold bins k and 512 - k, odd-group lanes 256 - k and 256 + k (k = k2 + 16 k1); D = 513
+                float *sw = s_aud + p.span + (lane >> 5) * D;
+                const int hh = (lane >> 4) & 1;
+#pragma unroll
+                for (int k1 = 0; k1 < 8; ++k1)
+                {
+                    const int k = k2 + 16 * k1;
+                    const f2 l = spec_log2((k == 0 && hh == 0) ? 4.0f * rawe : pa[k1], pb[k1]);
+                    sw[hh ? 256 - k : k] = l.x;
+                    if (hh) { sw[256 + k] = l.y; }
+                    else if (k > 0) { sw[512 - k] = l.y; }
+                    if (hh == 0 && k == 1) { sw[512] = l.y; }                                   // last bin := the one before (c/kaldi_spectrogram.c:245-247)
+                }
+                if (k2 == 0 && hh == 0) { const f2 l = spec_log2(pa[8], pb[8]); sw[128] = l.x; sw[384] = l.y; }
+            }
+            else if (PAIR)
             {
                 // pa[k1] / pb[k1]: bin k2 + 16 k1 of frames A / B (D = 129 columns each, B's row right behind A's)
                 float *sta = s_aud + p.span + 2 * f * D, *stb = sta + D;
@@ -116,6 +142,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(so + 4 * c);
                     __builtin_amdgcn_raw_buffer_store_b128(v, ry, c * 16, 0, 0);
                 }
+                if (WIDE && lane < 2) { const int i = 4 * (FW * D / 4) + lane; __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, so[i]), ry, i * 4, 0, 0); }      // 2 x 513 = 256 chunks + 2
             }
             else                                                            // the last quad of an utterance: fewer frames
             {
@@ -152,10 +179,27 @@ kernel_fn spectrogram_for_nz(int nz, bool dither, bool pcm)
     }
 }
 
+
+kernel_fn spectrogram_wide_for_nz(int nz, bool pcm)
+{
+    switch (nz)
+    {
+        case 9: return pcm ? fast_spectrogram_kernel<9, false, true, false, true> : fast_spectrogram_kernel<9, false, false, false, true>;
+        case 10: return pcm ? fast_spectrogram_kernel<10, false, true, false, true> : fast_spectrogram_kernel<10, false, false, false, true>;
+        case 11: return pcm ? fast_spectrogram_kernel<11, false, true, false, true> : fast_spectrogram_kernel<11, false, false, false, true>;
+        case 12: return pcm ? fast_spectrogram_kernel<12, false, true, false, true> : fast_spectrogram_kernel<12, false, false, false, true>;
+        case 13: return pcm ? fast_spectrogram_kernel<13, false, true, false, true> : fast_spectrogram_kernel<13, false, false, false, true>;
+        case 14: return pcm ? fast_spectrogram_kernel<14, false, true, false, true> : fast_spectrogram_kernel<14, false, false, false, true>;
+        case 15: return pcm ? fast_spectrogram_kernel<15, false, true, false, true> : fast_spectrogram_kernel<15, false, false, false, true>;
+        default: return pcm ? fast_spectrogram_kernel<16, false, true, false, true> : fast_spectrogram_kernel<16, false, false, false, true>;
+    }
+}
+
 }  // namespace
 
-kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair)
+kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide)
 {
+    if (wide) { return spectrogram_wide_for_nz(nz, pcm); }
     return pair ? spectrogram_for_nz<true>(nz, dither, pcm) : spectrogram_for_nz<false>(nz, dither, pcm);
 }
 

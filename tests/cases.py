@@ -72,6 +72,9 @@ for i, (kind, extra) in enumerate((("fbank", dict(B=80)), ("fbank", dict(B=40, a
     for j, (sr, snip, dc0, rawe) in enumerate(((22050.0, 1, 1, 1), (32000.0, 0, 0, 0), (24000.0, 0, 1, 0), (22050.0, 1, 0, 1))):
         _add(kind, [9000, 3000, 700, 12001][j], 620 + 4 * i + j, sr=sr, hif=sr / 2, snip=snip, dc0=dc0, raw_energy=rawe,
              win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j], **extra)
+for j, (sr, snip, dc0, rawe) in enumerate(((22050.0, 1, 1, 1), (32000.0, 0, 0, 0), (24000.0, 0, 1, 0), (22050.0, 1, 0, 1))):
+    _add("spectrogram", [9000, 3000, 700, 12001][j], 660 + j, sr=sr, snip=snip, dc0=dc0, raw_energy=rawe,
+         win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j])
 _add("mfcc", 1024, 650, sr=16000.0, fl=64.0, fs=16.0)            # L=1024 == nfft, one frame
 _add("fbank", 3000, 651, sr=16000.0, fl=32.0625, fs=10.0, B=23)   # L=513: the shortest 1024-point frame
 _add("mfcc", 3000, 605, sr=16000.0, fl=10.0, fs=5.0)             # L=160 -> nfft 256
