@@ -1,7 +1,7 @@
 // fast_kernels.hip -- host side of the tuned gfx950 fp32 kernels (fast_spectrogram.hip, fast_mel.hip; their shared
 // device code is fast_common.hpp): launch geometry, plan tables, launch.  The kernels serve 512-point frames (257..512
-// samples per frame, even frame shift) and 256-point frames (129..256 samples), two frames per complex transform.
-// Everything else runs on generic_kernels.hip.
+// samples per frame, even frame shift), 256-point frames (129..256 samples), two frames per complex transform, and
+// 1024-point frames (513..1024 samples, no dither), one frame per 32 lanes.  Everything else runs on generic_kernels.hip.
 #include "fast_common.hpp"
 #include <mutex>
 #include <set>

@@ -2,7 +2,7 @@
 //
 // One 256-thread workgroup walks a tile of consecutive frames of one utterance; the frame lives in
 // LDS from the gather to the feature epilogue.  This path serves the *_d entry points, frame lengths
-// without a tuned kernel (nfft other than 512) and odd frame shifts; the tuned fp32 kernels are in
+// without a tuned kernel (nfft other than 256, 512, 1024) and odd frame shifts; the tuned fp32 kernels are in
 // fast_spectrogram.hip / fast_mel.hip.  Pipeline order and arithmetic follow the reference's per-frame loop
 // (c/kaldi_mfcc.c:213-334; spectrogram epilogue c/kaldi_spectrogram.c:236-251; fbank epilogue
 // c/kaldi_fbank.c:290-350; PLP tail per SURVEY.md 8(a) row P).
