@@ -41,6 +41,7 @@ WORKLOADS = {
     # 1024-point frames (22.05 kHz audio, 551-sample frames): one frame per 32 lanes
     "fbank80_22kHz_1000x10s": dict(kind="fbank", opts=dict(sr=22050.0, B=80, lg=1, lof=20.0, hif=11025.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
     "spectrogram_22kHz_1000x10s": dict(kind="spectrogram", opts=dict(sr=22050.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
+    "mfcc13_22kHz_dither1_1000x10s": dict(kind="mfcc", opts=dict(sr=22050.0, B=23, C=13, Q=22.0, lof=20.0, hif=11025.0, **{**FRONT, "dither": 1.0}), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
     "mfcc13_22kHz_1000x10s": dict(kind="mfcc", opts=dict(sr=22050.0, B=23, C=13, Q=22.0, lof=20.0, hif=11025.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
     "plp13_1000x10s": dict(kind="plp", opts=dict(B=23, C=13, Q=22.0, compress=1.0 / 3.0, cep_scale=1.0, lof=20.0, hif=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
 }

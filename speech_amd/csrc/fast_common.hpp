@@ -496,9 +496,9 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
 // NZ = ceil(L / 64) rows of 64 samples hold data; fa = the frame's first sample in the slice.  With k = k2 + 16 k1, k1 < 8:
 //   even-group lanes: pa[k1] = 4 |X[k]|^2,     pb[k1] = 4 |X[512-k]|^2;  lane k2 = 0 also pa[8], pb[8] = bins 128, 384
 //   odd-group lanes:  pa[k1] = 4 |X[256-k]|^2, pb[k1] = 4 |X[256+k]|^2
-template <int NZ, bool HALF>
+template <int NZ, bool HALF, bool DITHER>
 __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
-                                                 float (&pa)[9], float (&pb)[9], float &rawe)
+                                                 const unsigned long long dkey, float (&pa)[9], float (&pb)[9], float &rawe)
 {
     const int n1 = lane & 15, h = (lane >> 4) & 1;
     const int L = p.L;
@@ -520,6 +520,21 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
         }
         else { z[n2] = f2{0.0f, 0.0f}; }
     }
+    if (DITHER)                                                             // c/kaldi_mfcc.c:243-262
+    {
+        // samples i00 + 64 n2 and that + 2 are the members of parity h of the Box-Muller pairs 2 n1 + 32 n2 and the next one
+        // (the lane of the other group draws the same pairs and takes the other member)
+        sum = 0.0f;
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            const unsigned pr = (unsigned)(2 * n1 + 32 * n2);
+            z[n2].x += dither_one(dither_bits(dkey, pr), p.dither, h);
+            z[n2].y += dither_one(dither_bits(dkey, pr + 1u), p.dither, h);
+            if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
+            sum += z[n2].x + z[n2].y;
+        }
+    }
     float mean = 0.0f;
     if (p.dc0)                                                              // c/kaldi_mfcc.c:265-271
     {
@@ -540,6 +555,31 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
 #pragma unroll
         for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
     }
+    if (DITHER)
+    {
+        // the dithered samples exist in registers only.  The sample before the lane's first one is the second one of the odd
+        // group's lane n1 - 1 (even group; lane 0: that of lane 15 one row up) or the first one of the even group's lane n1
+        // (odd group); the sample before its second one is the first (even group) / second (odd group) one of the other
+        // group's lane n1.
+        const int xa = (h ? (lane ^ 16) : ((lane & 32) | 16 | ((n1 - 1) & 15))) << 2, xb = (lane ^ 16) << 2;
+        float up = z[0].x;                                                  // l = 0: y[0] = d[0] - p d[0]
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            // what a lane SENDS: even-group lanes are asked for .x through xa and .y through xb, odd-group lanes the reverse
+            const float fa_ = __int_as_float(__builtin_amdgcn_ds_bpermute(xa, __float_as_int(h ? z[n2].y : z[n2].x)));
+            const float fb_ = __int_as_float(__builtin_amdgcn_ds_bpermute(xb, __float_as_int(h ? z[n2].x : z[n2].y)));
+            const float xp0 = (h == 0 && n1 == 0) ? up : fa_;
+            up = fa_;
+            const int i0 = i00 + 64 * n2;
+            f2 y;
+            y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
+            y.y = fmaf(npre, fb_, z[n2].y) * win[i0 + 2];
+            if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
+            z[n2] = y;
+        }
+    }
+    else
 #pragma unroll
     for (int n2 = 0; n2 < NZ; ++n2)
     {

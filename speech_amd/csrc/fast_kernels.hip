@@ -1,7 +1,7 @@
 // fast_kernels.hip -- host side of the tuned gfx950 fp32 kernels (fast_spectrogram.hip, fast_mel.hip; their shared
 // device code is fast_common.hpp): launch geometry, plan tables, launch.  The kernels serve 512-point frames (257..512
 // samples per frame, even frame shift), 256-point frames (129..256 samples), two frames per complex transform, and
-// 1024-point frames (513..1024 samples, no dither), one frame per 32 lanes.  Everything else runs on generic_kernels.hip.
+// 1024-point frames (513..1024 samples), one frame per 32 lanes.  Everything else runs on generic_kernels.hip.
 #include "fast_common.hpp"
 #include <mutex>
 #include <set>
@@ -21,8 +21,6 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return g; }
     g.pair = (nfft == (size_t)NFFT / 2u);
     g.wide = (nfft == 2u * (size_t)NFFT);
-    // 1024-point frames: without dither (dithered ones fall to the generic kernels)
-    if (g.wide && (float)o.dither > FLT_EPSILON) { return g; }
     g.fw = g.wide ? 2 : (g.pair ? 2 * QF : QF);
     g.nz = g.wide ? (int)((L + 63u) / 64u) : (g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u));
     const size_t F = nfft / 2u + 1u, rows = (g.wide ? 64u : (g.pair ? 16u : 32u)) * (size_t)g.nz;

@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const __amdgpu_bu
 template <int NZ, int KIND, int P, bool DITHER, bool PAIR, bool WIDE = false>
 __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
 {
-    static_assert(!(PAIR && WIDE) && !(WIDE && DITHER), "one mode at a time; the wide mode has no dithered form");
+    static_assert(!(PAIR && WIDE), "one mode at a time");
     constexpr int FWK = WIDE ? 2 : (PAIR ? 2 * QF : QF);                    // frames per wave
     constexpr int TILEK = MW * FWK;                                         // frames per workgroup
     constexpr int RTK = TILEK / 16;                                         // 16-frame row tiles
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (nfr > 0 && WIDE)
     {
         // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds; its row is never stored)
-        frame_power_wide<NZ, true>(s_aud + (lane >> 5) * p.stp, s_tab, s_tr, lane, p, pa, pb, rawe);
+        const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)),
+                                                                  (unsigned long long)((long long)tile.frame0 + fq + (lane >> 5))) : 0ull;
+        frame_power_wide<NZ, true, DITHER>(s_aud + (lane >> 5) * p.stp, s_tab, s_tr, lane, p, dkey, pa, pb, rawe);
     }
     else if (nfr > 0 && PAIR)
     {
@@ -327,18 +329,19 @@ kernel_fn mel_for_kind(int kind)
     }
 }
 
+template <bool DITHER>
 kernel_fn mel_wide_for_nz(int nz, int kind)
 {
     switch (nz)
     {
-        case 9: return mel_for_kind<9, false, false, true>(kind);
-        case 10: return mel_for_kind<10, false, false, true>(kind);
-        case 11: return mel_for_kind<11, false, false, true>(kind);
-        case 12: return mel_for_kind<12, false, false, true>(kind);
-        case 13: return mel_for_kind<13, false, false, true>(kind);
-        case 14: return mel_for_kind<14, false, false, true>(kind);
-        case 15: return mel_for_kind<15, false, false, true>(kind);
-        default: return mel_for_kind<16, false, false, true>(kind);
+        case 9: return mel_for_kind<9, DITHER, false, true>(kind);
+        case 10: return mel_for_kind<10, DITHER, false, true>(kind);
+        case 11: return mel_for_kind<11, DITHER, false, true>(kind);
+        case 12: return mel_for_kind<12, DITHER, false, true>(kind);
+        case 13: return mel_for_kind<13, DITHER, false, true>(kind);
+        case 14: return mel_for_kind<14, DITHER, false, true>(kind);
+        case 15: return mel_for_kind<15, DITHER, false, true>(kind);
+        default: return mel_for_kind<16, DITHER, false, true>(kind);
     }
 }
 
@@ -364,7 +367,7 @@ kernel_fn mel_for_nz(int nz, int kind, bool dither)
 
 kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide)
 {
-    if (wide) { return mel_wide_for_nz(nz, kind); }
+    if (wide) { return dither ? mel_wide_for_nz<true>(nz, kind) : mel_wide_for_nz<false>(nz, kind); }
     return pair ? mel_for_nz<true>(nz, kind, dither) : mel_for_nz<false>(nz, kind, dither);
 }
 

@@ -11,7 +11,7 @@ namespace {
 template <int NZ, bool DITHER, bool PCM, bool PAIR, bool WIDE = false>
 __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
 {
-    static_assert(!(PAIR && WIDE) && !(WIDE && DITHER), "one mode at a time; the wide mode has no dithered form");
+    static_assert(!(PAIR && WIDE), "one mode at a time");
     constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             if (WIDE)
             {
                 // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds and is dropped)
-                frame_power_wide<NZ, false>(s_aud + (lane >> 5) * p.stp, s_tab + opaque_zero(), s_tr, lane, p, pa, pb, rawe);
+                const unsigned long long dkey = DITHER ? dither_frame_key(dkey_utt, (unsigned long long)((long long)tile.frame0 + fq + (lane >> 5))) : 0ull;
+                frame_power_wide<NZ, false, DITHER>(s_aud + (lane >> 5) * p.stp, s_tab + opaque_zero(), s_tr, lane, p, dkey, pa, pb, rawe);
             }
             else if (PAIR)
             {
@@ -180,18 +181,25 @@ kernel_fn spectrogram_for_nz(int nz, bool dither, bool pcm)
 }
 
 
-kernel_fn spectrogram_wide_for_nz(int nz, bool pcm)
+template <int NZ>
+kernel_fn spectrogram_wide_for(bool dither, bool pcm)
+{
+    if (dither) { return pcm ? fast_spectrogram_kernel<NZ, true, true, false, true> : fast_spectrogram_kernel<NZ, true, false, false, true>; }
+    return pcm ? fast_spectrogram_kernel<NZ, false, true, false, true> : fast_spectrogram_kernel<NZ, false, false, false, true>;
+}
+
+kernel_fn spectrogram_wide_for_nz(int nz, bool dither, bool pcm)
 {
     switch (nz)
     {
-        case 9: return pcm ? fast_spectrogram_kernel<9, false, true, false, true> : fast_spectrogram_kernel<9, false, false, false, true>;
-        case 10: return pcm ? fast_spectrogram_kernel<10, false, true, false, true> : fast_spectrogram_kernel<10, false, false, false, true>;
-        case 11: return pcm ? fast_spectrogram_kernel<11, false, true, false, true> : fast_spectrogram_kernel<11, false, false, false, true>;
-        case 12: return pcm ? fast_spectrogram_kernel<12, false, true, false, true> : fast_spectrogram_kernel<12, false, false, false, true>;
-        case 13: return pcm ? fast_spectrogram_kernel<13, false, true, false, true> : fast_spectrogram_kernel<13, false, false, false, true>;
-        case 14: return pcm ? fast_spectrogram_kernel<14, false, true, false, true> : fast_spectrogram_kernel<14, false, false, false, true>;
-        case 15: return pcm ? fast_spectrogram_kernel<15, false, true, false, true> : fast_spectrogram_kernel<15, false, false, false, true>;
-        default: return pcm ? fast_spectrogram_kernel<16, false, true, false, true> : fast_spectrogram_kernel<16, false, false, false, true>;
+        case 9: return spectrogram_wide_for<9>(dither, pcm);
+        case 10: return spectrogram_wide_for<10>(dither, pcm);
+        case 11: return spectrogram_wide_for<11>(dither, pcm);
+        case 12: return spectrogram_wide_for<12>(dither, pcm);
+        case 13: return spectrogram_wide_for<13>(dither, pcm);
+        case 14: return spectrogram_wide_for<14>(dither, pcm);
+        case 15: return spectrogram_wide_for<15>(dither, pcm);
+        default: return spectrogram_wide_for<16>(dither, pcm);
     }
 }
 
@@ -199,7 +207,7 @@ kernel_fn spectrogram_wide_for_nz(int nz, bool pcm)
 
 kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide)
 {
-    if (wide) { return spectrogram_wide_for_nz(nz, pcm); }
+    if (wide) { return spectrogram_wide_for_nz(nz, dither, pcm); }
     return pair ? spectrogram_for_nz<true>(nz, dither, pcm) : spectrogram_for_nz<false>(nz, dither, pcm);
 }
 

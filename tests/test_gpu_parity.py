@@ -434,7 +434,9 @@ def test_dither_is_seeded_and_has_the_right_scale():
 @pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80, snip=0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("plp", {}),
                                     ("mfcc", dict(fl=17.0, preemph=0.0, dc0=0, raw_energy=0, use_energy=1)),
                                     ("mfcc", dict(sr=8000.0, hif=4000.0)), ("spectrogram", dict(sr=8000.0, snip=0)),
-                                    ("fbank", dict(sr=8000.0, hif=3800.0, B=40, fl=32.0, preemph=0.0))])
+                                    ("fbank", dict(sr=8000.0, hif=3800.0, B=40, fl=32.0, preemph=0.0)),
+                                    ("mfcc", dict(sr=22050.0, hif=11025.0)), ("spectrogram", dict(sr=32000.0, snip=0)),
+                                    ("fbank", dict(sr=24000.0, hif=12000.0, B=40, preemph=0.0, dc0=0, raw_energy=0, use_energy=1)), ("plp", dict(fl=64.0, fs=16.0))])
 def test_dithered_frames_tuned_and_generic_draw_the_same_noise(kind, o):
     """dither (c/kaldi_mfcc.c:243-262) is per frame and counter-based: the tuned kernels (noise added in registers, the
     pre-emphasis neighbour fetched across lanes) and the generic kernel (noise added in LDS) see the same dithered frames,
@@ -470,9 +472,10 @@ def test_which_plans_run_on_the_tuned_kernels():
              ("fbank", dict(fl=20.0)), ("mfcc", dict(fl=32.0, fs=16.0)), ("fbank", dict(B=23, hif=9000.0)), ("mfcc", dict(dither=0.5)),
              ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("spectrogram", dict(sr=8000.0)), ("plp", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(fl=10.0, fs=5.0, B=40)),
              ("fbank", dict(B=128)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100)),
-             ("fbank", dict(sr=22050.0, hif=11025.0, B=80)), ("mfcc", dict(sr=32000.0, hif=16000.0)), ("plp", dict(sr=24000.0, hif=12000.0)), ("mfcc", dict(fl=64.0, fs=20.0)), ("spectrogram", dict(sr=22050.0)), ("spectrogram", dict(sr=32000.0))]
-    generic = [("mfcc", dict(sr=4000.0, hif=2000.0, B=15)), ("spectrogram", dict(sr=44100.0)), ("spectrogram", dict(sr=22050.0, dither=1.0)), ("mfcc", dict(sr=16100.0)),
-               ("mfcc", dict(sr=22050.0, hif=11025.0, dither=1.0)), ("fbank", dict(sr=44100.0, hif=22050.0)),
+             ("fbank", dict(sr=22050.0, hif=11025.0, B=80)), ("mfcc", dict(sr=32000.0, hif=16000.0)), ("plp", dict(sr=24000.0, hif=12000.0)), ("mfcc", dict(fl=64.0, fs=20.0)), ("spectrogram", dict(sr=22050.0)), ("spectrogram", dict(sr=32000.0)),
+             ("mfcc", dict(sr=22050.0, hif=11025.0, dither=1.0)), ("spectrogram", dict(sr=22050.0, dither=1.0))]
+    generic = [("mfcc", dict(sr=4000.0, hif=2000.0, B=15)), ("spectrogram", dict(sr=44100.0)), ("mfcc", dict(sr=16100.0)),
+               ("fbank", dict(sr=44100.0, hif=22050.0)),
                ("plp", dict(order=16)), ("fbank", dict(B=129)), ("mfcc", dict(fs=10.0625)), ("fbank", dict(B=1))]
     for kind, o in tuned:
         assert api.Plan(kind, **o).tuned, (kind, o)
