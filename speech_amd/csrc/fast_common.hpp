@@ -812,8 +812,9 @@ __device__ __forceinline__ int quad_geom(const FastParams &p, const TileDesc &ti
 #ifndef ST_AUX
 #define ST_AUX 0
 #endif
+template <int NP = NPRE>
 struct Prefetch {
-    float v[NPRE];                      // float samples, or the raw 16-bit PCM words (converted when parked)
+    float v[NP];                      // float samples, or the raw 16-bit PCM words (converted when parked)
     bool on;
 };
 
@@ -821,31 +822,31 @@ struct Prefetch {
 // return 0 without touching memory).  Branching around the loads, or between a float and a PCM variant of them, makes the
 // register allocator join the variants through copies -- and a copy of a load's destination is a wait for the load, right
 // where it was issued.  Hence also PCM as a template parameter.
-template <bool PCM>
-__device__ __forceinline__ void prefetch_issue(Prefetch &pf, const FastParams &p, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane)
+template <bool PCM, int NP = NPRE>
+__device__ __forceinline__ void prefetch_issue(Prefetch<NP> &pf, const FastParams &p, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane)
 {
-    pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NPRE) && !(p.ablate & 2);
+    pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NP) && !(p.ablate & 2);
     if (PCM)
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu16 + (pf.on ? s0 : 0)), 0, pf.on ? need * 2 : 0, BUF_FLAGS);
 #pragma unroll
-        for (int j = 0; j < NPRE; ++j) { pf.v[j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, j * 128, 0)); }
+        for (int j = 0; j < NP; ++j) { pf.v[j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, j * 128, 0)); }
     }
     else
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + (pf.on ? s0 : 0)), 0, pf.on ? need * 4 : 0, BUF_FLAGS);
 #pragma unroll
-        for (int j = 0; j < NPRE; ++j) { pf.v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0)); }
+        for (int j = 0; j < NP; ++j) { pf.v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0)); }
     }
 }
 
-template <bool PCM>
-__device__ __forceinline__ void prefetch_park(const Prefetch &pf, float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane, int ablate)
+template <bool PCM, int NP = NPRE>
+__device__ __forceinline__ void prefetch_park(const Prefetch<NP> &pf, float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane, int ablate)
 {
     if (pf.on)
     {
 #pragma unroll
-        for (int j = 0; j < NPRE; ++j) { s_aud[lane + 64 * j] = PCM ? (float)(short)(unsigned short)__builtin_bit_cast(unsigned, pf.v[j]) : pf.v[j]; }
+        for (int j = 0; j < NP; ++j) { s_aud[lane + 64 * j] = PCM ? (float)(short)(unsigned short)__builtin_bit_cast(unsigned, pf.v[j]) : pf.v[j]; }
     }
     else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
 }

@@ -13,6 +13,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
 {
     static_assert(!(PAIR && WIDE), "one mode at a time");
     constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;
+    constexpr int NPK = WIDE ? 20 : NPRE;                                   // prefetch registers: 2 frames of a 1024-point plan span up to 1280 samples at 25 / 10 ms
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         const int fq = it * SUBF + wv * FW;                                  // this wave's quad in sub-tile `it`
         long long s0n; int needn;
         const int nfrn = quad_geom(p, tile, fq + SUBF, s0n, needn, FW);
-        Prefetch pf;
-        prefetch_issue<PCM>(pf, p, xu, xu16, s0n, needn, N, nfrn, lane);
+        Prefetch<NPK> pf;
+        prefetch_issue<PCM, NPK>(pf, p, xu, xu16, s0n, needn, N, nfrn, lane);
         float pa[9], pb[9], rawe = 1.0f;
         f2 rawe2 = {1.0f, 1.0f};
         if (nfr > 0)
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         // BEFORE this quad's stores are issued.  The loads were issued ahead of the whole FFT, and vmcnt retires in order,
         // so waiting for them here waits for nothing younger; the stores then drain behind the next quad's arithmetic.
         wave_sync();
-        prefetch_park<PCM>(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
+        prefetch_park<PCM, NPK>(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
         wave_sync();
         if (nfr > 0)
         {
