@@ -245,7 +245,9 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
             for (int r = 0; r < 4; ++r)
             {
                 const int fr = 16 * rt + fr0 + r;
-                if (c < p.C) { s_out[fr * p.C + c] = (p.use_energy && c == 0) ? pos_log(s_e[fr]) : acc[r]; }
+                // c0 := log energy (c/kaldi_mfcc.c:327); with C == 2 the last-cepstrum copy (:333) then takes the energy too
+                const bool en = p.use_energy && (c == 0 || (c == 1 && p.C == 2));
+                if (c < p.C) { s_out[fr * p.C + c] = en ? pos_log(s_e[fr]) : acc[r]; }
             }
         }
         __syncthreads();

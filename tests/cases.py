@@ -48,6 +48,10 @@ _add("mfcc", 2000, 500, B=23, C=13, Q=0.0)
 _add("mfcc", 2000, 501, B=23, C=23, Q=22.0)
 _add("mfcc", 2000, 502, B=23, C=2)
 _add("mfcc", 2000, 503, B=5, C=1)
+_add("mfcc", 2000, 504, B=23, C=2, use_energy=1)                 # the last-cepstrum copy takes the energy that replaced c0
+_add("mfcc", 2000, 505, B=23, C=2, use_energy=1, sr=8000.0, hif=4000.0)
+_add("mfcc", 3000, 506, B=23, C=2, use_energy=1, sr=32000.0, hif=16000.0, snip=0)
+_add("plp", 2000, 507, B=23, C=2, use_energy=1)
 _add("fbank", 2000, 510, amp=1, lg=1)
 _add("fbank", 2000, 511, amp=0, lg=0)
 _add("fbank", 2000, 512, amp=1, lg=0, use_energy=1)

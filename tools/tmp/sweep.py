@@ -1,0 +1,29 @@
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import signals
+from compare import max_err
+from test_fuzz import _configs
+from speech_amd import api
+worst = {}
+n = 0
+for seed in range(100, 160):
+    for kind, o, lens, L, stp in _configs(25, seed):
+        if o["sr"] != 32000.0: continue
+        for dither in (0.0, 2.0):
+            oo = dict(o, dither=dither, dither_seed=seed)
+            p0 = api.Plan(kind, **oo)
+            if not p0.tuned: continue
+            xs = [signals.utterance(m, 1000 + 7 * i + seed, sr=o["sr"], flat=True) for i, m in enumerate(lens)]
+            X = torch.from_numpy(np.concatenate(xs)).cuda()
+            outs = []
+            for fg in (0, 1):
+                plan = api.Plan(kind, force_generic=fg, **oo)
+                b = api.Batch(plan, lens); Y = torch.zeros(b.total_out, device="cuda"); b.run(X, Y); torch.cuda.synchronize()
+                outs.append(Y.cpu().numpy().reshape(-1, plan.D))
+            assert np.isfinite(outs[0]).all(), (seed, kind, oo)
+            e = max_err(kind, o, outs[0], outs[1])
+            key = (kind, o.get("lg", 1), dither > 0)
+            if e > worst.get(key, (0,))[0]: worst[key] = (e, seed, L, stp, o.get("B"))
+            n += 1
+print("configs", n)
+for k, v in sorted(worst.items(), key=str): print(k, v)
