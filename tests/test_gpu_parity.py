@@ -558,7 +558,7 @@ def test_extract_pcm16_equals_the_drop_in_call(dtype):
 
 @pytest.mark.parametrize("kind,o", [("spectrogram", {}), ("fbank", dict(B=80)), ("mfcc", dict(snip=0)), ("plp", {}),
                                     ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("fbank", dict(B=40, snip=0, force_generic=1)),
-                                    ("mfcc", dict(sr=22050.0, hif=11025.0, snip=0))])
+                                    ("mfcc", dict(sr=22050.0, hif=11025.0, snip=0)), ("spectrogram", dict(sr=32000.0, snip=0))])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_pcm16_input_equals_float_input(kind, o, dtype):
     """speech_batch_run_pcm16: int16 audio converted on load gives bit-identical features to the float path on the same
