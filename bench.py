@@ -4,16 +4,21 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" is one pass of the per-frame pipeline over one resident batch of synthetic 16 kHz audio.  The headline
-workload is BASELINE.json configs[1]: kaldi_spectrogram over 1,000 x 10 s utterances per GPU (inputs already in HBM,
-outputs left in HBM).  Utterances are independent, so ranks shard them with no collective ("weak" scaling: every rank
-owns 1,000 utterances); the only cross-rank step is the barrier + max over ranks of the elapsed time.
-Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
+One "step" is one pass of the per-frame pipeline (c/kaldi_fbank.c:208-351) over one resident batch of synthetic 16 kHz
+audio.  The headline workload is the one BASELINE.json's metric is quoted on, configs[2]: kaldi_fbank, 80 log-mel bins,
+over a ragged batch of 100,000 utterances of 1-30 s per GPU (99 GB of audio + 50 GB of features, resident in HBM).
+Utterances are independent, so ranks shard them with no collective ("weak" scaling: every rank owns 100,000 utterances,
+its part of an LPT assignment of N x 100,000); the only cross-rank steps are the barrier, the max over ranks of the
+elapsed time and the gather of the per-GPU figures.  Started WITHOUT a launcher and with --gpus N > 1 it starts the N
+ranks itself (fresh child processes, before the parent touches any GPU).  Rank 0 prints ONE JSON line; DESIGN.md
+section "Measurement" explains every field.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,33 +31,48 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 SR = 16000.0
 
 FRONT = dict(snip=1, dc0=1, raw_energy=1, preemph=0.97, win="povey")
+FBANK80 = dict(B=80, lg=1, lof=20.0, hif=8000.0, **FRONT)
+MFCC13 = dict(B=23, C=13, Q=22.0, lof=20.0, hif=8000.0, **FRONT)
+HIRES = dict(B=40, C=40, Q=22.0, lof=20.0, hif=7600.0, **FRONT)
+PLP13 = dict(B=23, C=13, Q=22.0, compress=1.0 / 3.0, cep_scale=1.0, lof=20.0, hif=8000.0, **FRONT)
 WORKLOADS = {
-    # BASELINE.json configs; the headline is configs[1]
+    # BASELINE.json configs; the headline is configs[2], the workload the metric names
+    "fbank80_100k_ragged_1-30s": dict(kind="fbank", opts=FBANK80, lens="ragged", nutt=100000),
     "spectrogram_1000x10s": dict(kind="spectrogram", opts=dict(**FRONT), lens="fixed", nutt=1000, secs=10.0),
-    "fbank80_ragged_1-30s": dict(kind="fbank", opts=dict(B=80, lg=1, lof=20.0, hif=8000.0, **FRONT), lens="ragged", nutt=2000),
-    "mfcc13_1000x10s": dict(kind="mfcc", opts=dict(B=23, C=13, Q=22.0, lof=20.0, hif=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
-    "mfcc_hires40_1000x10s": dict(kind="mfcc", opts=dict(B=40, C=40, Q=22.0, lof=20.0, hif=7600.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
+    "mfcc13_1000x10s": dict(kind="mfcc", opts=MFCC13, lens="fixed", nutt=1000, secs=10.0),
+    "mfcc_hires40_1000x10s": dict(kind="mfcc", opts=HIRES, lens="fixed", nutt=1000, secs=10.0),
+    "plp13_1000x10s": dict(kind="plp", opts=PLP13, lens="fixed", nutt=1000, secs=10.0),
+    "fbank80_ragged_1-30s": dict(kind="fbank", opts=FBANK80, lens="ragged", nutt=2000),
     # widening: the same spectrogram batch fed as 16-bit PCM (speech_batch_run_pcm16), 2 N + 4 W D bytes
     "spectrogram_pcm16_1000x10s": dict(kind="spectrogram", opts=dict(**FRONT), lens="fixed", nutt=1000, secs=10.0, pcm16=True),
-    "mfcc13_dither1_1000x10s": dict(kind="mfcc", opts=dict(B=23, C=13, Q=22.0, lof=20.0, hif=8000.0, **{**FRONT, "dither": 1.0}), lens="fixed", nutt=1000, secs=10.0),
-    "mfcc13_8kHz_1000x10s": dict(kind="mfcc", opts=dict(sr=8000.0, B=23, C=13, Q=22.0, lof=20.0, hif=4000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=8000.0),
-    "mfcc13_8kHz_dither1_1000x10s": dict(kind="mfcc", opts=dict(sr=8000.0, B=23, C=13, Q=22.0, lof=20.0, hif=4000.0, **{**FRONT, "dither": 1.0}), lens="fixed", nutt=1000, secs=10.0, sr=8000.0),
+    "mfcc13_dither1_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, dither=1.0), lens="fixed", nutt=1000, secs=10.0),
+    "mfcc13_8kHz_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=8000.0, hif=4000.0), lens="fixed", nutt=1000, secs=10.0, sr=8000.0),
+    "mfcc13_8kHz_dither1_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=8000.0, hif=4000.0, dither=1.0), lens="fixed", nutt=1000, secs=10.0, sr=8000.0),
     "spectrogram_8kHz_1000x10s": dict(kind="spectrogram", opts=dict(sr=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=8000.0),
     # 1024-point frames (22.05 kHz audio, 551-sample frames): one frame per 32 lanes
-    "fbank80_22kHz_1000x10s": dict(kind="fbank", opts=dict(sr=22050.0, B=80, lg=1, lof=20.0, hif=11025.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
+    "fbank80_22kHz_1000x10s": dict(kind="fbank", opts=dict(FBANK80, sr=22050.0, hif=11025.0), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
     "spectrogram_22kHz_1000x10s": dict(kind="spectrogram", opts=dict(sr=22050.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
-    "mfcc13_22kHz_dither1_1000x10s": dict(kind="mfcc", opts=dict(sr=22050.0, B=23, C=13, Q=22.0, lof=20.0, hif=11025.0, **{**FRONT, "dither": 1.0}), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
-    "mfcc13_22kHz_1000x10s": dict(kind="mfcc", opts=dict(sr=22050.0, B=23, C=13, Q=22.0, lof=20.0, hif=11025.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
-    "plp13_1000x10s": dict(kind="plp", opts=dict(B=23, C=13, Q=22.0, compress=1.0 / 3.0, cep_scale=1.0, lof=20.0, hif=8000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0),
+    "mfcc13_22kHz_dither1_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=22050.0, hif=11025.0, dither=1.0), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
+    "mfcc13_22kHz_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=22050.0, hif=11025.0), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),
 }
-HEADLINE = "spectrogram_1000x10s"
+HEADLINE = "fbank80_100k_ragged_1-30s"
+HEADLINE_TEXT = ("kaldi_fbank, 80 log-mel bins, on a ragged batch of 100,000 16 kHz utterances of 1-30 s per GPU, 25/10 ms frames, "
+                 "512-pt FFT (BASELINE.json configs[2])")
+WAVE_AUDIO_S = 1.0e6           # corpus leg: audio-seconds per wave (64 GB of float32 audio + 16 GB of hires features in HBM)
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r2_counters.json")       # written by tools/pmc_to_json.py from rocprofv3 --pmc passes
 
 
-def lengths(w, rank):
+def lengths(w, rank, world, nutt):
     if w["lens"] == "fixed":
-        return np.full(w["nutt"], int(w["secs"] * w.get("sr", SR)), dtype=np.uint64)
-    rng = np.random.default_rng(0x5EED2026 + rank)
-    return rng.integers(16000, 480001, size=w["nutt"]).astype(np.uint64)     # 1-30 s, SURVEY.md 8(d) config 3
+        return np.full(nutt, int(w["secs"] * w.get("sr", SR)), dtype=np.uint64)
+    # 1-30 s, SURVEY.md 8(d) config 3.  N ranks: one list of N x nutt lengths, dealt to the ranks by api.shard_utterances
+    # (longest first to the least loaded rank; no utterance is split) -- every rank derives the same assignment by itself
+    rng = np.random.default_rng(0x5EED2026)
+    allens = rng.integers(16000, 480001, size=nutt * world).astype(np.int64)
+    if world == 1:
+        return allens.astype(np.uint64)
+    from speech_amd import api
+    return allens[api.shard_utterances(allens, world)[rank]].astype(np.uint64)
 
 
 def synth_audio(total, device, seed):
@@ -64,29 +84,30 @@ def synth_audio(total, device, seed):
     chunk = 1 << 26
     for i in range(0, total, chunk):
         n = min(chunk, total - i)
-        t = torch.arange(i, i + n, device=device, dtype=torch.float32)
+        t = (torch.arange(i, i + n, device=device, dtype=torch.int64) % 16000).to(torch.float32)    # whole-Hz tones repeat every second: exact phase however long the array
         x[i:i + n] = (1000.0 * torch.randn(n, device=device, generator=g)
                       + 3000.0 * torch.sin(t * (2 * np.pi * 440.0 / SR)) + 1500.0 * torch.sin(t * (2 * np.pi * 2750.0 / SR)))
     return x
 
 
 class Work:
-    def __init__(self, name, device, rank):
+    def __init__(self, name, device, rank=0, world=1, nutt=None):
         import torch
         from speech_amd import api
         self.name = name
         w = WORKLOADS[name]
         self.kind = w["kind"]
         self.opts = w["opts"]
+        self.sr = w.get("sr", SR)
         self.plan = api.Plan(w["kind"], device=device.index, **w["opts"])
-        self.lens = lengths(w, rank)
+        self.lens = lengths(w, rank, world, nutt or w["nutt"])
         self.batch = api.Batch(self.plan, self.lens)
         self.X = synth_audio(self.batch.total_samples, device, 1234 + rank)
         self.pcm16 = bool(w.get("pcm16"))
         if self.pcm16:
             self.X = self.X.round().clamp(-32767, 32767).to(torch.int16)
         self.Y = torch.zeros(self.batch.total_out, device=device, dtype=torch.float32)
-        self.audio_s = float(self.batch.total_samples) / w.get("sr", SR)
+        self.audio_s = float(self.batch.total_samples) / self.sr
         # algorithmic bytes per launch: read every sample once, write every feature once
         self.bytes = (2.0 if self.pcm16 else 4.0) * self.batch.total_samples + 4.0 * self.batch.total_out
 
@@ -117,7 +138,6 @@ class Work:
 
 def cpu_baseline(work, budget_s=10.0):
     """The CPU oracle (oracle/, fast-FFT mode, -O3) timed on this host over a bounded sample of the same workload."""
-    import subprocess
     so = os.path.join(ROOT, "oracle", "liboracle_native.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
@@ -215,42 +235,125 @@ def pcie_inclusive(work, device, nutt=64):
     return float(b.total_samples) / SR / dt
 
 
+def corpus_waves(device, hours, steps_note=None):
+    """BASELINE.json configs[3] on one GPU: hires MFCC (40 mel / 40 ceps) over `hours` of synthetic audio walked in HBM-sized
+    waves (speech_amd.corpus), every wave generated on the device by the integer generator and never materialised on the
+    host; only the extraction launches are timed (HIP events), the generator beside them."""
+    from speech_amd import corpus
+    spec = corpus.SyntheticCorpus(hours=hours, seed=0x5EED2026)
+    r = corpus.run_synthetic(spec, "mfcc", HIRES, device=device.index, wave_audio_s=WAVE_AUDIO_S, keep_output=False, pcm16=False)
+    by = 4.0 * r["samples"] + 4.0 * r["features"]
+    return {"workload": "kaldi_mfcc hires (40 mel / 40 ceps) on %.0f h of synthetic 16 kHz audio = 1/%d of BASELINE.json configs[3]'s 10k-hour corpus, "
+                        "%d waves of <= %.0f audio-s (float32, resident) generated on the device" % (hours, round(10000.0 / hours), r["waves"], WAVE_AUDIO_S),
+            "audio_s": r["audio_s"], "utterances": r["utterances"], "extract_ms_total": r["kernel_ms"], "generate_ms_total": r["generate_ms"],
+            "audio_s_per_s_per_gpu": r["audio_s"] / (r["kernel_ms"] * 1e-3), "roofline_frac_hbm": by / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "wall_s_incl_generation": r["wall_s"], "ten_k_hours_on_8_gpus_s_extrapolated": r["kernel_ms"] * 1e-3 * (10000.0 / hours) / 8.0}
+
+
+def utilisation(workload):
+    """VALU / MFMA utilisation and HBM traffic of the workload's dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r2_counters.json, produced by tools/profile_round.sh + tools/pmc_to_json.py on the same bench command)."""
+    try:
+        return json.load(open(COUNTERS_JSON)).get(workload, {})
+    except Exception:
+        return {}
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start N fresh ranks of this script (the parent makes no GPU call), wait for them."""
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1" or os.environ.get("BENCH_LAUNCH_TEST") == "1"
+    if not rehearsal:
+        import torch
+        ndev = torch.cuda.device_count()                               # does not initialise the GPU
+        if ndev < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (BENCH_REHEARSAL=1 runs every rank on GPU 0 with gloo)\n" % (n, ndev))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("BENCH_SPAWN_TIMEOUT", "1500"))
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is not None:
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+        if (rc or time.time() > deadline) and pending:                  # a rank failed (or hung): stop the others, by PID
+            for p in pending:
+                p.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--nutt", type=int, default=0, help="utterances per GPU (default: the workload's own; rehearsals on one GPU need fewer)")
+    ap.add_argument("--corpus-hours", type=float, default=1250.0, help="size of the wave-streamed hires-MFCC corpus leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / other workloads (profiling runs)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- lets the N>1 code path be exercised on a one-GPU box
-    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
-    device = torch.device("cuda", 0 if rehearsal else local_rank)
-    torch.cuda.set_device(device)
+    import torch
+    import torch.distributed as dist
+    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- lets the N>1 code path be exercised on a one-GPU box.
+    # BENCH_LAUNCH_TEST=1 (tests/test_bench_launcher.py, CPU): the ranks form the gloo group and report, without any GPU work.
+    launch_test = os.environ.get("BENCH_LAUNCH_TEST") == "1"
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1" or launch_test
     if world > 1:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=device)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if launch_test:
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_test": True, "n_gpus": world, "max_rank_plus_1": float(t.item())}))
+        return
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
+    torch.cuda.set_device(device)
+    cpu_group = rehearsal
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            if rehearsal:
+            if cpu_group:
                 dist.barrier()
             else:
                 dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    work = Work(args.workload, device, rank)
+    nutt = args.nutt or WORKLOADS[args.workload]["nutt"]
+    if rehearsal and world > 1 and not args.nutt:
+        nutt = max(1, nutt // (2 * world))                            # the ranks share ONE GPU's HBM
+    work = Work(args.workload, device, rank, world, nutt)
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(args.warmup):
         work.step(stream)
@@ -266,33 +369,36 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     k_avg = ev0.elapsed_time(ev1) / args.steps
+    mine = [elapsed, work.audio_s, k_avg, float(work.bytes)]
+    per = [mine]
     if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if rehearsal else device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor(mine, device="cpu" if cpu_group else device, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)                                       # bookkeeping only: 4 doubles per rank
+        per = [[float(v) for v in a.cpu()] for a in allt]
+    elapsed = max(p[0] for p in per)                                   # MAX over ranks
+    total_audio_s = sum(p[1] for p in per)
 
     out = None
     if rank == 0:
         k_iso, k_min = work.kernel_ms(stream)
         achieved = work.bytes / (k_avg * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # written from rocprofv3 --pmc passes, see profiles/README.md
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        u = utilisation(args.workload)
         out = {
-            "metric": "audio-sec processed/sec (RTF^-1), 16 kHz", "value": world * work.audio_s * args.steps / elapsed, "unit": "audio-s/s",
+            "metric": "audio-sec processed/sec (RTF^-1), 16 kHz", "value": total_audio_s * args.steps / elapsed, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "kaldi_spectrogram on 1,000 x 10 s 16 kHz utterances per GPU, 25/10 ms frames, 512-pt FFT power spectrum (BASELINE.json configs[1])"
-                       if args.workload == HEADLINE else args.workload,
+            "config": {"workload": HEADLINE_TEXT if args.workload == HEADLINE and nutt == WORKLOADS[HEADLINE]["nutt"] else "%s (%d utterances per GPU)" % (args.workload, nutt),
                        "utterances_per_gpu": int(len(work.lens)), "audio_s_per_gpu": work.audio_s, "frames_per_gpu": int(work.batch.total_frames),
-                       "feature_dim": int(work.plan.D), "tuned_kernel": bool(work.plan.tuned), "sharding": "utterances over ranks, no collective"},
+                       "feature_dim": int(work.plan.D), "tuned_kernel": bool(work.plan.tuned), "rehearsal_on_one_gpu": bool(rehearsal and world > 1),
+                       "sharding": "utterances over ranks (LPT on sample counts), no collective on the data path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms_avg": k_avg, "kernel_ms_isolated_avg": k_iso, "kernel_ms_isolated_min": k_min,
+                         "traffic": u.get("hbm_bytes_per_launch"), "valu_util": u.get("valu_util"), "mfma_util": u.get("mfma_util"),
+                         "lds_bank_conflict_frac": u.get("lds_bank_conflict_frac"), "counters_from": u.get("source"),
+                         "kernel_ms_avg": k_avg, "kernel_ms_isolated_avg": k_iso, "kernel_ms_isolated_min": k_min,
                          "algorithmic_bytes_per_launch": work.bytes},
+            "per_gpu": [{"rank": r, "audio_s_per_s": p[1] * args.steps / p[0], "kernel_ms_avg": p[2], "audio_s": p[1],
+                         "roofline_frac_hbm": p[3] / (p[2] * 1e-3) / 1e9 / HBM_PEAK_GBS} for r, p in enumerate(per)],
         }
         if not args.no_extras and world == 1:       # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(work)
@@ -305,7 +411,7 @@ def main():
         for name in WORKLOADS:
             if name == HEADLINE:
                 continue
-            w = Work(name, device, rank)
+            w = Work(name, device)
             for _ in range(2):
                 w.step(stream)
             torch.cuda.synchronize()
@@ -313,11 +419,14 @@ def main():
             kw = w.sustained_ms(args.steps)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.steps
+            uo = utilisation(name)
             others[name] = {"audio_s_per_s_per_gpu": w.audio_s / dt, "kernel_ms_avg": kw, "roofline_frac_hbm": w.bytes / (kw * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "tuned_kernel": bool(w.plan.tuned)}
+                            "valu_util": uo.get("valu_util"), "mfma_util": uo.get("mfma_util"), "tuned_kernel": bool(w.plan.tuned)}
             w.free()
             torch.cuda.empty_cache()
         out["other_workloads_1gpu"] = others
+        if args.corpus_hours > 0:
+            out["corpus_hires_mfcc_1gpu"] = corpus_waves(device, args.corpus_hours)
     if world > 1:
         barrier()
         dist.destroy_process_group()

@@ -139,6 +139,24 @@ int speech_batch_splice(speech_batch *batch, const void *Y_dev, void *Z_dev, int
 int speech_batch_splice_subsample(speech_batch *batch, const void *Y_dev, void *Z_dev, int left, int right, int n, int offset, void *stream);
 int speech_batch_subsample_rows(const speech_batch *batch, int n, int offset, size_t *rows, size_t *total_rows);
 
+/* Dither of the ten drop-in functions (include/codee_speech.h).  The reference seeds its generator from the wall clock on
+   every call (c/kaldi_fbank.c:97-101), so no two calls add the same noise; here a dithered drop-in call draws the noise of
+   utterance number k of a counter-based generator under `seed`, k = 0, 1, 2, ... counting the dithered drop-in calls of the
+   process (default seed 0x5EED2026).  utt >= 0 pins k = utt for every following call (reproducible runs; a caller that
+   extracts a corpus one call per utterance passes the utterance's number before each call); utt < 0 returns to the counter
+   and restarts it at 0.  Process-wide; the batch ABI is not affected (speech_opts.dither_seed, speech_batch_set_ids). */
+void speech_set_dropin_dither(unsigned long long seed, long long utt);
+
+/* Bench / test support (no counterpart in the reference): fill the batch's packed audio X_dev (the plan's dtype, or int16
+   when pcm16 != 0) with the synthetic corpus of SURVEY.md 8(d) -- an integer-only counter-based generator (near-Gaussian
+   noise at about -29 dBFS plus three triangle tones per utterance, int16 scale), so that host (speech_amd/corpus.py) and
+   device produce the same samples bit for bit and a 10k-hour corpus never has to exist on the host.  Utterance u of the
+   batch is corpus utterance ids[u] (host array of nutt; NULL: u).  Enqueues on `stream` (waits for it first when ids is
+   given).  The batch must use its default dense packing or offsets that do not overlap. */
+int speech_batch_synth_audio(speech_batch *batch, void *X_dev, int pcm16, unsigned long long seed, const unsigned long long *ids, void *stream);
+/* The same generator on the host (no device needed): samples 0 .. n-1 of corpus utterance `utt` as int16. */
+int speech_synth_audio_host(unsigned long long seed, unsigned long long utt, size_t n, short *out);
+
 #ifdef __cplusplus
 }
 #endif

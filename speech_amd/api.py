@@ -160,6 +160,13 @@ class Plan:
                 if W is None:
                     raise SpeechError("an utterance of %d samples is not valid for this plan" % x.size)
                 ys.append(np.zeros((W, self.D), dtype=self.np_dtype))
+        else:
+            if len(ys) != n:
+                raise ValueError("out must hold one array per utterance")
+            for x, y in zip(xs, ys):
+                W = self.num_frames(x.size)                   # None: the C side rejects the utterance with the reference's message
+                if W is not None and (not isinstance(y, np.ndarray) or y.dtype != self.np_dtype or not y.flags.c_contiguous or y.size < W * self.D):
+                    raise ValueError("out arrays must be C-contiguous %s arrays of at least W x D = %d x %d elements" % (np.dtype(self.np_dtype).name, W, self.D))
         Xp = (C.c_void_p * max(1, n))(*[x.ctypes.data for x in xs])
         Yp = (C.c_void_p * max(1, n))(*[y.ctypes.data if y.size else xs[0].ctypes.data for y in ys])
         Np = (C.c_size_t * max(1, n))(*[x.size for x in xs])
@@ -183,6 +190,22 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def _dev_ptr(t, what, plan, numel, dtypes=None):
+    """data_ptr() of a torch tensor after checking what the C ABI cannot: device, dtype, contiguity and size (a wrong
+    tensor would otherwise be a GPU memory fault, not an error)."""
+    name = str(t.dtype).replace("torch.", "")
+    want = dtypes or ("float64" if plan.np_dtype == np.float64 else "float32",)
+    if not t.is_cuda or (t.device.index or 0) != plan.device:
+        raise ValueError("%s must be on cuda:%d (the plan's device), got %s" % (what, plan.device, t.device))
+    if name not in want:
+        raise ValueError("%s must have dtype %s, got %s" % (what, " or ".join(want), name))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % what)
+    if t.numel() < numel:
+        raise ValueError("%s holds %d elements, the batch needs %d" % (what, t.numel(), numel))
+    return C.c_void_p(t.data_ptr())
 
 
 class Batch:
@@ -212,28 +235,48 @@ class Batch:
         if self.nutt:
             self._lib.speech_batch_offsets(h, self.x_off.ctypes.data_as(pz), self.y_off.ctypes.data_as(pz), self.n_frames.ctypes.data_as(pz))
         self.n_samples = n
+        # one past the last element the kernels touch in X / Y (checked against the tensors handed to run)
+        self._x_end = int((self.x_off + n).max()) if self.nutt else 0
+        self._y_end = int((self.y_off + self.n_frames * np.uint64(plan.D)).max()) if self.nutt else 0
 
     def run(self, X, Y, stream=None, timed=False):
         """X, Y: torch tensors on the plan's device (1-D, plan dtype; X may also be int16 PCM).  stream: a raw hipStream_t value
         (e.g. torch.cuda.current_stream().cuda_stream) or None for the default stream."""
         sp = C.c_void_p(stream) if stream else None
+        need_x = int(self._x_end) if self.nutt else 0
+        need_y = int(self._y_end) if self.nutt else 0
+        yp = _dev_ptr(Y, "Y", self.plan, need_y)
         if str(X.dtype).endswith("int16"):
             # 16-bit PCM on the device (speech_batch_run_pcm16): converted to the plan's dtype as it is loaded
             ms = C.c_float()
-            rc = self._lib.speech_batch_run_pcm16(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()), sp, C.byref(ms) if timed else None)
+            rc = self._lib.speech_batch_run_pcm16(self._h, _dev_ptr(X, "X", self.plan, need_x, ("int16",)), yp, sp, C.byref(ms) if timed else None)
             if rc != 0:
                 raise SpeechError(_lib.last_error())
             return ms.value if timed else None
+        xp = _dev_ptr(X, "X", self.plan, need_x)
         if timed:
             ms = C.c_float()
-            rc = self._lib.speech_batch_run_timed(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()), sp, C.byref(ms))
+            rc = self._lib.speech_batch_run_timed(self._h, xp, yp, sp, C.byref(ms))
             if rc != 0:
                 raise SpeechError(_lib.last_error())
             return ms.value
-        rc = self._lib.speech_batch_run(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()), sp)
+        rc = self._lib.speech_batch_run(self._h, xp, yp, sp)
         if rc != 0:
             raise SpeechError(_lib.last_error())
         return None
+
+    def synth_audio(self, X, seed=0x5EED2026, ids=None, stream=None):
+        """fill X (plan dtype, or int16) with the synthetic corpus of SURVEY.md 8(d), generated on the device: utterance u of
+        the batch is corpus utterance ids[u] (default u); the same samples as corpus.synth_utterance gives on the host"""
+        pcm = str(X.dtype).endswith("int16")
+        xp = _dev_ptr(X, "X", self.plan, int(self._x_end) if self.nutt else 0, ("int16",) if pcm else None)
+        idp = None
+        if ids is not None:
+            ida = np.ascontiguousarray(ids, dtype=np.uint64)
+            if ida.shape != (self.nutt,):
+                raise ValueError("ids must have one entry per utterance")
+            idp = ida.ctypes.data_as(C.POINTER(C.c_ulonglong))
+        self._check(self._lib.speech_batch_synth_audio(self._h, xp, int(pcm), int(seed), idp, C.c_void_p(stream) if stream else None))
 
     # ---- corpus post-processing on the packed features (include/speech_hip.h, SURVEY.md 8(f4)) ----
 
@@ -246,13 +289,13 @@ class Batch:
         D = self.plan.D
         s, q, n = np.zeros(D), np.zeros(D), C.c_ulonglong()
         pd = C.POINTER(C.c_double)
-        self._check(self._lib.speech_batch_stats(self._h, C.c_void_p(Y.data_ptr()), s.ctypes.data_as(pd), q.ctypes.data_as(pd), C.byref(n),
+        self._check(self._lib.speech_batch_stats(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), s.ctypes.data_as(pd), q.ctypes.data_as(pd), C.byref(n),
                                                  C.c_void_p(stream) if stream else None))
         return s, q, int(n.value)
 
     def cmvn(self, Y, norm_vars=False, stream=None):
         """per-utterance mean (and variance) normalisation, in place"""
-        self._check(self._lib.speech_batch_cmvn(self._h, C.c_void_p(Y.data_ptr()), int(bool(norm_vars)), C.c_void_p(stream) if stream else None))
+        self._check(self._lib.speech_batch_cmvn(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), int(bool(norm_vars)), C.c_void_p(stream) if stream else None))
 
     def affine(self, Y, scale, offset, stream=None):
         """y = y * scale[d] + offset[d] in place (e.g. corpus-wide CMVN from merged stats)"""
@@ -261,17 +304,17 @@ class Batch:
         if sc.shape != (D,) or of.shape != (D,):
             raise ValueError("scale and offset must have shape (%d,)" % D)
         pd = C.POINTER(C.c_double)
-        self._check(self._lib.speech_batch_affine(self._h, C.c_void_p(Y.data_ptr()), sc.ctypes.data_as(pd), of.ctypes.data_as(pd),
+        self._check(self._lib.speech_batch_affine(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), sc.ctypes.data_as(pd), of.ctypes.data_as(pd),
                                                   C.c_void_p(stream) if stream else None))
 
     def add_deltas(self, Y, Z, order=2, window=2, stream=None):
         """Z (total_out * (order + 1) elements) = features with delta .. delta^order appended, Kaldi add-deltas"""
-        self._check(self._lib.speech_batch_add_deltas(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(order), int(window),
+        self._check(self._lib.speech_batch_add_deltas(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), _dev_ptr(Z, "Z", self.plan, self._y_end * (int(order) + 1)), int(order), int(window),
                                                       C.c_void_p(stream) if stream else None))
 
     def splice(self, Y, Z, left=4, right=4, stream=None):
         """Z (total_out * (left + right + 1) elements) = frames spliced with their neighbours, Kaldi splice-feats"""
-        self._check(self._lib.speech_batch_splice(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(left), int(right),
+        self._check(self._lib.speech_batch_splice(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), _dev_ptr(Z, "Z", self.plan, self._y_end * (int(left) + int(right) + 1)), int(left), int(right),
                                                   C.c_void_p(stream) if stream else None))
 
     def set_ids(self, ids=None):
@@ -293,7 +336,8 @@ class Batch:
     def splice_subsample(self, Y, Z, left=0, right=0, n=3, offset=0, stream=None):
         """Z (subsample_rows(n, offset)[1] * D * (left + right + 1) elements, utterances back to back) = every n-th spliced
         frame from `offset`: Kaldi splice-feats | subsample-feats in one pass"""
-        self._check(self._lib.speech_batch_splice_subsample(self._h, C.c_void_p(Y.data_ptr()), C.c_void_p(Z.data_ptr()), int(left), int(right),
+        need_z = self.subsample_rows(n, offset)[1] * self.plan.D * (int(left) + int(right) + 1)
+        self._check(self._lib.speech_batch_splice_subsample(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), _dev_ptr(Z, "Z", self.plan, need_z), int(left), int(right),
                                                             int(n), int(offset), C.c_void_p(stream) if stream else None))
 
     def close(self):

@@ -12,6 +12,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <type_traits>
@@ -249,6 +251,8 @@ struct speech_batch {
     std::vector<unsigned long long> zrow;
     int zrow_n, zrow_off;
     int yoff_pow2;               // largest of 1, 2, 4 that divides every utterance's output offset (-1: not computed yet)
+    unsigned long long *d_ids;   // speech_batch_synth_audio: the utterances' corpus numbers (allocated on first use)
+    unsigned long long max_n;    // longest utterance, samples
     size_t total_samples, total_out, total_frames;
     hipEvent_t ev0, ev1;
 };
@@ -532,7 +536,44 @@ int speech_batch_create(speech_batch **out, speech_plan *p, size_t nutt, const s
 
 }  // extern "C"
 
-// utterance u draws its dither as utterance number uids[u], or uid_base + u when uids is null
+// Host-side geometry of a batch: utterance and tile descriptors, totals.  Utterance u draws its dither as utterance number
+// uids[u], or uid_base + u when uids is null.  Fills `b` (whose vectors keep their capacity: the drop-in path reuses one per
+// thread); touches no device memory.
+int speech::batch_fill(speech_batch *b, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base,
+                       const unsigned int *uids)
+{
+    const char *fn = "speech_batch_create";
+    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_mom = nullptr; b->d_zrow = nullptr; b->zrow_n = b->zrow_off = -1; b->yoff_pow2 = -1; b->ev0 = b->ev1 = nullptr;
+    b->d_ids = nullptr; b->max_n = 0;
+    b->total_samples = b->total_out = b->total_frames = 0;
+    b->tiles.clear(); b->zrow.clear();
+    const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : GENERIC_TILE_FRAMES;
+    const char *kfn = kind_name(p->o.kind, p->o.dtype);
+    b->utts.resize(nutt);
+    size_t xo = 0, yo = 0;
+    for (size_t u = 0; u < nutt; ++u)
+    {
+        const size_t N = n_samples[u];
+        size_t W = 0;
+        if (N < 1u) { return fail(kfn, "N (nsamps in signal) must be positive"); }
+        if (p->o.snip_edges && p->sz.L > N) { return fail(kfn, "frame length must be < signal length if snip_edges"); }
+        if (speech_plan_num_frames(p, N, &W)) { return fail(kfn, "utterance %zu: %zu samples not supported (int-indexed)", u, N); }
+        UttDesc d;
+        d.x_off = x_off ? x_off[u] : xo; d.n = N; d.y_off = y_off ? y_off[u] : yo; d.W = W;
+        b->utts[u] = d;
+        xo += N; yo += W * p->sz.D;
+        b->total_samples += N; b->total_out += W * p->sz.D; b->total_frames += W;
+        if (N > b->max_n) { b->max_n = N; }
+        for (size_t f0 = 0; f0 < W; f0 += (size_t)tile)
+        {
+            TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.uid = uids ? (uint32_t)uids[u] : uid_base + (uint32_t)u;
+            b->tiles.push_back(t);
+        }
+    }
+    if (b->tiles.size() > 0x7FFFFFFFull) { return fail(fn, "batch too large for one launch (%zu tiles)", b->tiles.size()); }
+    return 0;
+}
+
 int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base,
                          const unsigned int *uids)
 {
@@ -542,31 +583,7 @@ int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const 
     if (nutt > 0xFFFFFFFFull) { return fail(fn, "too many utterances"); }
     speech_batch *b = new (std::nothrow) speech_batch();
     if (!b) { return fail(fn, "out of host memory"); }
-    b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_mom = nullptr; b->d_zrow = nullptr; b->zrow_n = b->zrow_off = -1; b->yoff_pow2 = -1; b->ev0 = b->ev1 = nullptr;
-    b->total_samples = b->total_out = b->total_frames = 0;
-    const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : GENERIC_TILE_FRAMES;
-    const char *kfn = kind_name(p->o.kind, p->o.dtype);
-    b->utts.resize(nutt);
-    size_t xo = 0, yo = 0;
-    for (size_t u = 0; u < nutt; ++u)
-    {
-        const size_t N = n_samples[u];
-        size_t W = 0;
-        if (N < 1u) { delete b; return fail(kfn, "N (nsamps in signal) must be positive"); }
-        if (p->o.snip_edges && p->sz.L > N) { delete b; return fail(kfn, "frame length must be < signal length if snip_edges"); }
-        if (speech_plan_num_frames(p, N, &W)) { delete b; return fail(kfn, "utterance %zu: %zu samples not supported (int-indexed)", u, N); }
-        UttDesc d;
-        d.x_off = x_off ? x_off[u] : xo; d.n = N; d.y_off = y_off ? y_off[u] : yo; d.W = W;
-        b->utts[u] = d;
-        xo += N; yo += W * p->sz.D;
-        b->total_samples += N; b->total_out += W * p->sz.D; b->total_frames += W;
-        for (size_t f0 = 0; f0 < W; f0 += (size_t)tile)
-        {
-            TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.uid = uids ? (uint32_t)uids[u] : uid_base + (uint32_t)u;
-            b->tiles.push_back(t);
-        }
-    }
-    if (b->tiles.size() > 0x7FFFFFFFull) { delete b; return fail(fn, "batch too large for one launch (%zu tiles)", b->tiles.size()); }
+    if (batch_fill(b, p, nutt, n_samples, x_off, y_off, uid_base, uids)) { delete b; return 1; }
     DeviceGuard g(p->device);
     if (!g.ok) { delete b; return fail(fn, "cannot select device %d", p->device); }
     hipError_t e = hipSuccess;
@@ -574,6 +591,9 @@ int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const 
     if (e == hipSuccess && nutt) { e = hipMemcpy(b->d_utts, b->utts.data(), nutt * sizeof(UttDesc), hipMemcpyHostToDevice); }
     if (e == hipSuccess && !b->tiles.empty()) { e = hipMalloc((void **)&b->d_tiles, b->tiles.size() * sizeof(TileDesc)); }
     if (e == hipSuccess && !b->tiles.empty()) { e = hipMemcpy(b->d_tiles, b->tiles.data(), b->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice); }
+    // mn0 plans run the moments pass inside speech_batch_run: its buffer belongs to batch creation, so that the run itself
+    // only launches (and can be captured in a HIP graph)
+    if (e == hipSuccess && nutt && p->o.mn0) { e = hipMalloc((void **)&b->d_mom, mom_doubles(nutt, p->sz.D) * sizeof(double)); }
     if (e != hipSuccess) { speech_batch_destroy(b); return fail(fn, "device allocation failed: %s", hipGetErrorString(e)); }
     *out = b;
     return 0;
@@ -596,6 +616,7 @@ void speech_batch_destroy(speech_batch *b)
     if (b->d_tiles) { (void)hipFree(b->d_tiles); }
     if (b->d_mom) { (void)hipFree(b->d_mom); }
     if (b->d_zrow) { (void)hipFree(b->d_zrow); }
+    if (b->d_ids) { (void)hipFree(b->d_ids); }
     if (b->ev0) { (void)hipEventDestroy(b->ev0); }
     if (b->ev1) { (void)hipEventDestroy(b->ev1); }
     delete b;
@@ -700,6 +721,34 @@ int speech_batch_cmvn(speech_batch *b, void *Y, int norm_vars, void *stream)
     if (post_moments(fn, b, Y, &pp, s)) { return 1; }
     pp.Y = Y; pp.mode = 1; pp.norm_vars = norm_vars ? 1 : 0;
     HIP_TRY(fn, launch_post(POST_AFFINE, b->plan->o.dtype == SPEECH_F64, pp, mw, s));
+    return 0;
+}
+
+int speech_batch_synth_audio(speech_batch *b, void *X, int pcm16, unsigned long long seed, const unsigned long long *ids, void *stream)
+{
+    const char *fn = "speech_batch_synth_audio";
+    if (!b || !b->plan) { return fail(fn, "null batch"); }
+    if (b->utts.empty()) { return 0; }
+    if (!X) { return fail(fn, "null device pointer"); }
+    DeviceGuard g(b->plan->device);
+    if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
+    hipStream_t s = (hipStream_t)stream;
+    if (ids)
+    {
+        if (!b->d_ids) { HIP_TRY(fn, hipMalloc((void **)&b->d_ids, b->utts.size() * sizeof(unsigned long long))); }
+        HIP_TRY(fn, hipMemcpyAsync(b->d_ids, ids, b->utts.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        HIP_TRY(fn, hipStreamSynchronize(s));                                // ids may be pageable and leave scope
+    }
+    const int elem = pcm16 ? 2 : (b->plan->o.dtype == SPEECH_F64 ? 8 : 4);
+    HIP_TRY(fn, launch_synth(X, elem, b->d_utts, ids ? b->d_ids : nullptr, (uint32_t)b->utts.size(), b->max_n, seed, s));
+    return 0;
+}
+
+int speech_synth_audio_host(unsigned long long seed, unsigned long long utt, size_t n, short *out)
+{
+    if (!out && n) { return fail("speech_synth_audio_host", "null pointer"); }
+    const SynthUtt s = synth_utt(seed, utt);
+    for (size_t i = 0; i < n; ++i) { out[i] = (short)synth_sample(s, (unsigned)i); }
     return 0;
 }
 
@@ -828,10 +877,16 @@ int speech_batch_splice_subsample(speech_batch *b, const void *Y, void *Z, int l
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-// The reference rebuilds its tables on every call (c/kaldi_mfcc.c:105-210).  Here a call looks its option set up in a
-// small process-wide cache of plans (plans are immutable once built, so threads share them) and stages through
-// per-thread device buffers that only grow, so that repeated calls cost two copies and one launch.
-struct PlanCacheEntry { speech_opts o; int device; speech_plan *plan; unsigned long long stamp; };
+// The reference rebuilds its tables on every call (c/kaldi_mfcc.c:105-210) and frees all it allocated before it returns
+// (:355-357).  Here a call looks its option set up in a small process-wide cache of plans (plans are immutable once built,
+// so threads share them) and stages through per-thread buffers that only grow, so that repeated calls cost two copies and
+// one launch.  Cache entries and calls in flight hold the plan by shared_ptr: an evicted plan is destroyed, with its device
+// tables, as soon as the last call that uses it has returned.
+struct PlanCacheEntry { speech_opts o; int device; std::shared_ptr<speech_plan> plan; unsigned long long stamp; };
+// dither of the drop-in calls (speech_set_dropin_dither): seed, pinned utterance number (< 0: none), call counter
+std::atomic<unsigned long long> g_dropin_seed{0x5EED2026ull};
+std::atomic<long long> g_dropin_utt{-1};
+std::atomic<uint32_t> g_dropin_counter{0u};
 std::mutex g_cache_mu;
 std::vector<PlanCacheEntry> g_cache;
 unsigned long long g_cache_clock = 0;
@@ -846,45 +901,59 @@ bool same_opts(const speech_opts &a, const speech_opts &b)
            a.lpc_order == b.lpc_order && a.mn0 == b.mn0 && a.dither_seed == b.dither_seed && a.force_generic == b.force_generic;
 }
 
-speech_plan *cached_plan(const speech_opts &o, int dev)
+std::shared_ptr<speech_plan> cached_plan(const speech_opts &o, int dev)
 {
+    std::shared_ptr<speech_plan> evicted;                                    // destroyed (if this was its last holder) after the lock is gone
     std::lock_guard<std::mutex> lk(g_cache_mu);
     for (auto &e : g_cache) { if (e.device == dev && same_opts(e.o, o)) { e.stamp = ++g_cache_clock; return e.plan; } }
     speech_plan *p = nullptr;
     if (speech_plan_create(&p, &o, dev)) { return nullptr; }
+    std::shared_ptr<speech_plan> sp(p, [](speech_plan *q) { speech_plan_destroy(q); });
     if (g_cache.size() >= PLAN_CACHE_MAX)
     {
-        // The least recently used plan is dropped from the table but not destroyed: another thread may be running it.
-        // At most one plan per distinct option set ever used is kept alive, a few KB of tables each.
         size_t lru = 0;
         for (size_t i = 1; i < g_cache.size(); ++i) { if (g_cache[i].stamp < g_cache[lru].stamp) { lru = i; } }
+        evicted = std::move(g_cache[lru].plan);
         g_cache.erase(g_cache.begin() + (long)lru);
     }
-    g_cache.push_back(PlanCacheEntry{o, dev, p, ++g_cache_clock});
-    return p;
+    g_cache.push_back(PlanCacheEntry{o, dev, sp, ++g_cache_clock});
+    return sp;
 }
 
-struct StageBuffers { void *dX = nullptr, *dY = nullptr; size_t capX = 0, capY = 0; int device = -1; };
+// Per-thread staging of the drop-in calls: device buffers for [descriptors | audio] and the features, a pinned pair for
+// small transfers ("stage through a pinned pool"), the mn0 moments, a stream.  Grow-only; freed when the
+// thread exits, or when the thread moves to another device.
+constexpr size_t PIN_MAX = (size_t)8 << 20;                                  // larger transfers go straight from / to the caller's memory
+struct StageBuffers {
+    void *dX = nullptr, *dY = nullptr, *hX = nullptr, *hY = nullptr; double *dMom = nullptr;
+    size_t capX = 0, capY = 0, caphX = 0, caphY = 0, capMom = 0;
+    hipStream_t st = nullptr;
+    int device = -1;
+    speech_batch batch;                                                      // geometry of the call in flight (vectors keep their capacity)
+    void release()
+    {
+        if (device < 0) { return; }
+        DeviceGuard g(device);
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        if (dX) { (void)hipFree(dX); } if (dY) { (void)hipFree(dY); } if (dMom) { (void)hipFree(dMom); }
+        if (hX) { (void)hipHostFree(hX); } if (hY) { (void)hipHostFree(hY); }
+        dX = dY = hX = hY = nullptr; dMom = nullptr; st = nullptr;
+        capX = capY = caphX = caphY = capMom = 0; device = -1;
+    }
+    ~StageBuffers() { release(); }
+};
 
-int stage_reserve(const char *fn, StageBuffers &sb, int dev, size_t bytesX, size_t bytesY)
+int stage_grow(const char *fn, void **p, size_t *cap, size_t bytes, bool pinned)
 {
-    if (sb.device != dev) { sb = StageBuffers(); sb.device = dev; }          // buffers of another device stay with that device
-    if (bytesX > sb.capX)
-    {
-        if (sb.dX) { (void)hipFree(sb.dX); sb.dX = nullptr; sb.capX = 0; }
-        const size_t cap = bytesX + bytesX / 4;
-        if (hipMalloc(&sb.dX, cap) != hipSuccess) { return fail(fn, "problem with hipMalloc"); }
-        sb.capX = cap;
-    }
-    if (bytesY > sb.capY)
-    {
-        if (sb.dY) { (void)hipFree(sb.dY); sb.dY = nullptr; sb.capY = 0; }
-        const size_t cap = bytesY + bytesY / 4;
-        if (hipMalloc(&sb.dY, cap) != hipSuccess) { return fail(fn, "problem with hipMalloc"); }
-        sb.capY = cap;
-    }
+    if (bytes <= *cap) { return 0; }
+    if (*p) { (void)(pinned ? hipHostFree(*p) : hipFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t want = bytes + bytes / 4;
+    if ((pinned ? hipHostMalloc(p, want, hipHostMallocDefault) : hipMalloc(p, want)) != hipSuccess) { *p = nullptr; return fail(fn, pinned ? "problem with hipHostMalloc" : "problem with hipMalloc"); }
+    *cap = want;
     return 0;
 }
+
+inline size_t up256(size_t n) { return (n + 255u) & ~(size_t)255; }
 
 // X16 non-null: the audio is 16-bit PCM on the host (speech_extract_pcm16), X unused
 template <typename T>
@@ -902,30 +971,57 @@ int legacy_call(speech_opts &o, T *Y, const T *X, size_t N, const short *X16 = n
     if ((!X && !X16) || !Y) { return fail(fn, "null pointer"); }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { return fail(fn, "no HIP device available (this library has no CPU fallback)"); }
-    speech_plan *p = cached_plan(o, dev);
-    if (!p) { return 1; }
+    const bool dithered = (T)o.dither > (T)FLT_EPSILON;                      // c/kaldi_mfcc.c:243
+    const std::shared_ptr<speech_plan> plan = cached_plan(o, dev);           // held until this call returns
+    if (!plan) { return 1; }
+    speech_plan *p = plan.get();
     static thread_local StageBuffers sb;
-    const size_t nout = W * sz.D;
+    if (sb.device != dev) { sb.release(); sb.device = dev; }
+    if (!sb.st && hipStreamCreateWithFlags(&sb.st, hipStreamNonBlocking) != hipSuccess) { sb.st = nullptr; return fail(fn, "problem creating a stream"); }
+    // the reference draws fresh noise on every call (wall-clock seed, c/kaldi_fbank.c:97-101): a dithered drop-in call takes
+    // the next number of a process-wide counter as its utterance number, unless the caller pinned one (speech_set_dropin_dither)
+    uint32_t uid = 0u;
+    if (dithered) { const long long pin = g_dropin_utt.load(); uid = pin >= 0 ? (uint32_t)pin : g_dropin_counter.fetch_add(1u); }
+    speech_batch &b = sb.batch;
+    if (batch_fill(&b, p, 1u, &N, nullptr, nullptr, uid, nullptr)) { return 1; }
+    const size_t nout = W * sz.D, ybytes = nout * sizeof(T);
     const size_t xbytes = X16 ? N * sizeof(short) : N * sizeof(T);
-    if (stage_reserve(fn, sb, dev, xbytes, nout * sizeof(T))) { return 1; }
-    speech_batch *b = nullptr;
-    int rc = 1;
-    do
+    const size_t tbytes = b.tiles.size() * sizeof(TileDesc);
+    const size_t dbytes = up256(sizeof(UttDesc) + tbytes);                   // [UttDesc | tiles] in front of the audio
+    const bool pinX = xbytes <= PIN_MAX, pinY = ybytes <= PIN_MAX;
+    if (stage_grow(fn, &sb.dX, &sb.capX, dbytes + xbytes, false) || stage_grow(fn, &sb.dY, &sb.capY, ybytes, false) ||
+        stage_grow(fn, &sb.hX, &sb.caphX, dbytes + (pinX ? xbytes : 0u), true) || (pinY && stage_grow(fn, &sb.hY, &sb.caphY, ybytes, true))) { return 1; }
+    if (p->o.mn0 && stage_grow(fn, (void **)&sb.dMom, &sb.capMom, mom_doubles(1u, sz.D) * sizeof(double), false)) { return 1; }
+    memcpy(sb.hX, b.utts.data(), sizeof(UttDesc));
+    memcpy((char *)sb.hX + sizeof(UttDesc), b.tiles.data(), tbytes);
+    const void *xsrc = X16 ? (const void *)X16 : (const void *)X;
+    hipError_t e;
+    if (pinX)
     {
-        if (speech_batch_create(&b, p, 1u, &N, nullptr, nullptr)) { break; }
-        if (hipMemcpy(sb.dX, X16 ? (const void *)X16 : (const void *)X, xbytes, hipMemcpyHostToDevice) != hipSuccess) { fail(fn, "problem copying X to the device"); break; }
-        if (X16 ? speech_batch_run_pcm16(b, (const short *)sb.dX, sb.dY, nullptr, nullptr) : speech_batch_run(b, sb.dX, sb.dY, nullptr)) { break; }
-        if (hipMemcpy(Y, sb.dY, nout * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) { fail(fn, "kernel execution or copy of Y failed"); break; }
-        rc = 0;
-    } while (0);
-    if (b) { speech_batch_destroy(b); }
-    return rc;
+        memcpy((char *)sb.hX + dbytes, xsrc, xbytes);
+        e = hipMemcpyAsync(sb.dX, sb.hX, dbytes + xbytes, hipMemcpyHostToDevice, sb.st);
+    }
+    else
+    {
+        e = hipMemcpyAsync(sb.dX, sb.hX, dbytes, hipMemcpyHostToDevice, sb.st);
+        if (e == hipSuccess) { e = hipMemcpyAsync((char *)sb.dX + dbytes, xsrc, xbytes, hipMemcpyHostToDevice, sb.st); }
+    }
+    if (e != hipSuccess) { return fail(fn, "problem copying X to the device (%s)", hipGetErrorString(e)); }
+    b.d_utts = (UttDesc *)sb.dX; b.d_tiles = (TileDesc *)((char *)sb.dX + sizeof(UttDesc)); b.d_mom = sb.dMom;     // borrowed: never freed through the batch
+    const void *dXa = (const char *)sb.dX + dbytes;
+    if (X16 ? speech_batch_run_pcm16(&b, (const short *)dXa, sb.dY, (void *)sb.st, nullptr) : speech_batch_run(&b, dXa, sb.dY, (void *)sb.st)) { return 1; }
+    e = hipMemcpyAsync(pinY ? sb.hY : (void *)Y, sb.dY, ybytes, hipMemcpyDeviceToHost, sb.st);
+    if (e == hipSuccess) { e = hipStreamSynchronize(sb.st); }
+    if (e != hipSuccess) { return fail(fn, "kernel execution or copy of Y failed (%s)", hipGetErrorString(e)); }
+    if (pinY) { memcpy(Y, sb.hY, ybytes); }
+    return 0;
 }
 
 template <typename T>
 void front(speech_opts &o, int kind, T sr, T fl, T fs, int snip, T dither, int dc0, int raw_energy, T preemph, const char *win, int mn0)
 {
     speech_opts_default(&o, kind);
+    o.dither_seed = g_dropin_seed.load();                                    // speech_set_dropin_dither
     o.dtype = std::is_same<T, double>::value ? SPEECH_F64 : SPEECH_F32;
     o.sr = (double)sr; o.frame_length = (double)fl; o.frame_shift = (double)fs; o.snip_edges = snip; o.dither = (double)dither;
     o.dc0 = dc0; o.raw_energy = raw_energy; o.preemph = (double)preemph; o.mn0 = mn0;
@@ -933,6 +1029,13 @@ void front(speech_opts &o, int kind, T sr, T fl, T fs, int snip, T dither, int d
 }
 
 }  // namespace
+
+extern "C" void speech_set_dropin_dither(unsigned long long seed, long long utt)
+{
+    g_dropin_seed.store(seed);
+    g_dropin_utt.store(utt);
+    if (utt < 0) { g_dropin_counter.store(0u); }
+}
 
 extern "C" int speech_extract_pcm16(const speech_opts *opts, const short *X16, size_t N, void *Y)
 {

@@ -70,6 +70,43 @@ __device__ __forceinline__ float dither_one(unsigned h, float scale, int odd)
     const float R = scale * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(1.0f - u1));
     return R * __builtin_amdgcn_sinf(u2 + (odd ? 0.0f : 0.25f));
 }
+// Synthetic corpus audio: integer arithmetic only, so any machine produces the same waveform.  Sample n of
+// corpus utterance `utt` under master seed `seed`:
+//   ku    = mix64(seed ^ utt)
+//   noise = (sum of the four 14-bit fields of mix64(ku ^ n * 0xD6E8FEB86659FD93) - 32766) >> 3      near-Gaussian, ~ -29 dBFS
+//   tone k (k = 0, 1, 2), from r_k = mix64(ku + k + 1): a triangle wave on a 32-bit phase accumulator,
+//           phase = lo32(r_k) + n * inc_k,  inc_k = 0x0147AE14 + (hi32(r_k) * 0x71EB851F >> 32)       80 .. 7200 Hz at 16 kHz
+//           t = phase >> 16;  tri = t < 32768 ? t : 65535 - t;  tone = (tri - 16384) * amp_k >> 14,  amp_k = 500 + (r_k >> 20 & 2047)
+//   sample = noise + tone_0 + tone_1 + tone_2        (|sample| < 12 000: int16 scale, as Kaldi waveforms)
+// speech_amd/corpus.py holds the numpy statement of the same lines; tests compare the two bit for bit.
+struct SynthUtt { unsigned long long ku; unsigned ph[3], inc[3]; int amp[3]; };
+__host__ __device__ __forceinline__ SynthUtt synth_utt(unsigned long long seed, unsigned long long utt)
+{
+    SynthUtt s;
+    s.ku = mix64(seed ^ utt);
+    for (int k = 0; k < 3; ++k)
+    {
+        const unsigned long long r = mix64(s.ku + (unsigned long long)(k + 1));
+        s.ph[k] = (unsigned)r;
+        s.inc[k] = 0x0147AE14u + (unsigned)(((r >> 32) * 0x71EB851Full) >> 32);
+        s.amp[k] = 500 + (int)((r >> 20) & 2047ull);
+    }
+    return s;
+}
+__host__ __device__ __forceinline__ int synth_sample(const SynthUtt &s, unsigned n)
+{
+    const unsigned long long h = mix64(s.ku ^ ((unsigned long long)n * 0xD6E8FEB86659FD93ull));
+    int v = (int)((h & 0x3FFFull) + ((h >> 14) & 0x3FFFull) + ((h >> 28) & 0x3FFFull) + ((h >> 42) & 0x3FFFull)) - 32766;
+    v >>= 3;                                                                 // arithmetic: floor
+    for (int k = 0; k < 3; ++k)
+    {
+        const unsigned t = (s.ph[k] + n * s.inc[k]) >> 16;
+        const int tri = (int)(t < 32768u ? t : 65535u - t);
+        v += ((tri - 16384) * s.amp[k]) >> 14;
+    }
+    return v;
+}
+
 __device__ __forceinline__ void dither_pair(unsigned h, double scale, double &g0, double &g1)
 {
     const double u1 = (double)(h >> 16) * 1.52587890625e-05;
@@ -119,6 +156,8 @@ struct FrameParams {
 // host layer (speech_api.hip), for host_pipeline.hip
 int fail(const char *fn, const char *fmt, ...);                             // records and prints "error in <fn>: ...", returns 1
 void plan_info(const speech_plan *p, int *device, int *dtype, size_t *D);
+int batch_fill(speech_batch *b, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base,
+               const unsigned int *uids);
 int batch_create(speech_batch **out, speech_plan *p, size_t nutt, const size_t *n_samples, const size_t *x_off, const size_t *y_off, uint32_t uid_base,
                  const unsigned int *uids);
 
@@ -144,6 +183,10 @@ hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_fra
 constexpr int POST_REDUCE_GROUP = 64;
 // out[g][c] = sum of in[64 g .. 64 g + 63][c] in row order; out holds ceil(n / 64) rows
 hipError_t launch_reduce_rows(const double *in, double *out, size_t n, int cols, hipStream_t s);
+
+// synthetic corpus audio (synth_kernels.hip): elem = bytes per sample of X (2: int16, 4: float, 8: double)
+hipError_t launch_synth(void *X, int elem, const UttDesc *utts, const unsigned long long *ids, uint32_t nutt, unsigned long long max_n,
+                        unsigned long long seed, hipStream_t s);
 
 // launchers (defined in the kernel translation units)
 hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s);
