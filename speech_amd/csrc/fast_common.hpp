@@ -230,18 +230,27 @@ __device__ __forceinline__ float pos_log(float v)
 
 __device__ __forceinline__ float floor_log(float v) { return pos_log(fmaxf(v, FLT_EPSILON)); }
 
-// spectrogram: log(max(q / 4, FLT_EPSILON)) with v_log_f32 on the whole value (absolute error ~2e-6 at q ~ 1e9; the
-// spectrogram tolerance is 1e-5) -- three instructions per bin
+// spectrogram: log(max(q / 4, FLT_EPSILON)) for q = 4 |X|^2, exponent and mantissa split as in pos_log: v_log_f32 on the
+// whole value is 1 ulp of log2(q) ~ 2e-6 at q ~ 1e9, which measured as 1.2-1.4 x the float32 CPU arithmetic's rms distance
+// from float64 (profiles/r2_parity_table.md, round 2); split, the hardware log only sees [0.5, 1) and the one rounding that
+// remains is the result's own.  ln(q / 4) = e ln2 + (log2(m) - 2) ln2 with q = m 2^e.
 __device__ __forceinline__ float spec_log(float q)
 {
-    return fmaf(__log2f(fmaxf(q, 4.0f * FLT_EPSILON)), 0.69314718055994530942f, -1.38629436111989061883f);
+    const float v = fmaxf(q, 4.0f * FLT_EPSILON);
+    const float m = __builtin_amdgcn_frexp_mantf(v);
+    const float e = (float)__builtin_amdgcn_frexp_expf(v);
+    return fmaf(e, 0.69314718055994530942f, fmaf(__log2f(m), 0.69314718055994530942f, -1.38629436111989061883f));
 }
 
-// two bins at a time: the scale-and-shift is one v_pk_fma_f32 (5 instructions per pair instead of 6)
+// two bins at a time: both scale-and-shift steps are v_pk_fma_f32 (12 instructions per pair)
 __device__ __forceinline__ f2 spec_log2(float qa, float qb)
 {
-    const f2 l = {__log2f(fmaxf(qa, 4.0f * FLT_EPSILON)), __log2f(fmaxf(qb, 4.0f * FLT_EPSILON))};
-    return __builtin_elementwise_fma(l, f2{0.69314718055994530942f, 0.69314718055994530942f}, f2{-1.38629436111989061883f, -1.38629436111989061883f});
+    const float va = fmaxf(qa, 4.0f * FLT_EPSILON), vb = fmaxf(qb, 4.0f * FLT_EPSILON);
+    const f2 l = {__log2f(__builtin_amdgcn_frexp_mantf(va)), __log2f(__builtin_amdgcn_frexp_mantf(vb))};
+    const f2 e = {(float)__builtin_amdgcn_frexp_expf(va), (float)__builtin_amdgcn_frexp_expf(vb)};
+    const f2 ln2 = {0.69314718055994530942f, 0.69314718055994530942f};
+    const f2 t = __builtin_elementwise_fma(l, ln2, f2{-1.38629436111989061883f, -1.38629436111989061883f});
+    return __builtin_elementwise_fma(e, ln2, t);
 }
 
 // Load the wave's audio slice: `need` samples starting at utterance-relative position s0 (may be negative or run past N

@@ -84,11 +84,6 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     float *s_ac = s_out + ((TILEK * p.D + 3) & ~3);
     for (int i = tid; i < TABK; i += NTM) { s_tab[i] = p.tab[i]; }
 
-    if ((p.ablate & 128) && blockIdx.x < 768u)                                // diagnostics: de-phase the first workgroups of a CU
-    {
-        const int slot = (int)(blockIdx.x >> 8) * (p.ablate >> 8);
-        for (int i = 0; i < slot; ++i) { __builtin_amdgcn_s_sleep(127); }
-    }
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
     const int fq = wv * FWK;

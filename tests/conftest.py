@@ -52,4 +52,4 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         import json
         with open(os.path.join(out, "parity_clauses.json"), "w") as f:
             json.dump({"checks": len(log), "clause1": n1, "clause2": n2, "failed": n0,
-                       "clause2_cases": [dict(label=str(r[0]), kind=r[1], e_go=r[3], e_gt=r[4], e_ot=r[5]) for r in log if r[2] == 2]}, f, indent=1)
+                       "clause2_cases": [dict(label=str(r[0]), kind=r[1], e_go=r[3], e_gt=r[4], e_ot=r[5], rms_ratio=r[6]) for r in log if r[2] == 2]}, f, indent=1)

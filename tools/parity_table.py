@@ -44,8 +44,8 @@ def row(label, kind, o, x):
     tol = 1e-5 if (kind == "spectrogram" and not mn0) else 1e-4
     n0 = len(compare.PARITY_LOG)
     ok, e_go, e_gt, e_ot = compare.check_parity(kind, o, got, ref, tr, tol=tol, oracle_fast=reff, label=label)
-    clause = compare.PARITY_LOG[n0][2]
-    return dict(case=label, kind=kind, tol=tol, e_go=e_go, e_gt=e_gt, e_ot=e_ot, e_ff=compare.max_err(kind, o, reff, ref), clause=clause,
+    clause, ratio = compare.PARITY_LOG[n0][2], compare.PARITY_LOG[n0][6]
+    return dict(rms_ratio=ratio, case=label, kind=kind, tol=tol, e_go=e_go, e_gt=e_gt, e_ot=e_ot, e_ff=compare.max_err(kind, o, reff, ref), clause=clause,
                 strict_bound=max(tol, compare.float32_floor(kind, o, ref, reff, tr)))
 
 
@@ -63,7 +63,7 @@ def main():
     n = len(rows)
     n1, n2, n0 = (sum(1 for r in rows if r["clause"] == k) for k in (1, 2, 0))
     summ = dict(cases=n, clause1=n1, clause2=n2, failed=n0, margin=compare.MARGIN, cap_factor=compare.CAP_FACTOR,
-                worst_ratio_e_gt_over_e_ot=max((r["e_gt"] / r["e_ot"] for r in rows if r["clause"] != 1 and r["e_ot"] > 0), default=None),
+                worst_rms_ratio=max((r["rms_ratio"] for r in rows), default=None), worst_ratio_e_gt_over_e_ot=max((r["e_gt"] / r["e_ot"] for r in rows if r["clause"] != 1 and r["e_ot"] > 0), default=None),
                 worst_e_go_over_tol_clause2=max((r["e_go"] / r["tol"] for r in rows if r["clause"] == 2), default=None),
                 strict_violations=[r["case"] for r in rows if r["e_go"] > r["strict_bound"]])
     json.dump(dict(summary=summ, rows=rows), open(out + ".json", "w"), indent=1)
@@ -71,11 +71,11 @@ def main():
         f.write("# Parity table (tools/parity_table.py, MI355X)\n\n")
         f.write("e_go = HIP vs oracle, e_gt = HIP vs float64 statement, e_ot = float32 CPU (oracle, exact or float FFT, the larger) vs float64, "
                 "e_ff = oracle float FFT vs oracle exact FFT; unit: tests/compare.max_err.  Clause 1: e_go <= tol.  Clause 2: "
-                "e_gt <= max(tol, %.2f e_ot) and e_go <= %.0f tol.  strict bound = max(tol, largest distance among the three CPU evaluations).\n\n" % (compare.MARGIN, compare.CAP_FACTOR))
+                "rms(HIP - f64) <= %.2f rms(f32 CPU - f64) [column rms ratio], e_gt <= max(tol, %.1f e_ot) and e_go <= %.0f tol.  strict bound = max(tol, largest distance among the three CPU evaluations).\n\n" % (compare.MARGIN, compare.MAX_MARGIN, compare.CAP_FACTOR))
         f.write("%d cases: %d by clause 1, %d by clause 2, %d failed; cases with e_go above the strict bound: %d\n\n" % (n, n1, n2, n0, len(summ["strict_violations"])))
-        f.write("| case | tol | e_go | e_gt | e_ot | e_ff | strict bound | clause |\n|---|---|---|---|---|---|---|---|\n")
+        f.write("| case | tol | e_go | e_gt | e_ot | e_ff | rms ratio | strict bound | clause |\n|---|---|---|---|---|---|---|---|---|\n")
         for r in rows:
-            f.write("| %s | %.0e | %.2e | %.2e | %.2e | %.2e | %.2e | %d |\n" % (r["case"], r["tol"], r["e_go"], r["e_gt"], r["e_ot"], r["e_ff"], r["strict_bound"], r["clause"]))
+            f.write("| %s | %.0e | %.2e | %.2e | %.2e | %.2e | %.2f | %.2e | %d |\n" % (r["case"], r["tol"], r["e_go"], r["e_gt"], r["e_ot"], r["e_ff"], r["rms_ratio"], r["strict_bound"], r["clause"]))
     print(json.dumps(summ))
 
 
