@@ -139,6 +139,15 @@ int speech_batch_splice(speech_batch *batch, const void *Y_dev, void *Z_dev, int
 int speech_batch_splice_subsample(speech_batch *batch, const void *Y_dev, void *Z_dev, int left, int right, int n, int offset, void *stream);
 int speech_batch_subsample_rows(const speech_batch *batch, int n, int offset, size_t *rows, size_t *total_rows);
 
+/* speech_batch_cmvn for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+   forbid hipMalloc.  No counterpart in the reference (its mn0 pass, c/kaldi_fbank.c:355-370, works in the caller's Y).
+   Same arguments and the same result, bit for bit, as speech_batch_cmvn; the per-utterance moments ([nutt][2][D] doubles)
+   live in a static device array of 4 MiB per GPU instead of a buffer the batch allocates on first use, and the call makes
+   no hipMalloc / hipFree and no other allocating call.  Batches that need more (nutt x 2 x D > 524 288) are rejected with a
+   message: use speech_batch_cmvn.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams,
+   two threads) race; calls on one stream are ordered and safe.  Nothing in the array has to start at zero. */
+int speech_batch_cmvn_noalloc(speech_batch *batch, void *Y_dev, int norm_vars, void *stream);
+
 /* Dither of the ten drop-in functions (include/codee_speech.h).  The reference seeds its generator from the wall clock on
    every call (c/kaldi_fbank.c:97-101), so no two calls add the same noise; here a dithered drop-in call draws the noise of
    utterance number k of a counter-based generator under `seed`, k = 0, 1, 2, ... counting the dithered drop-in calls of the

@@ -24,7 +24,7 @@ EXT_SYMBOLS = [
     "speech_batch_run", "speech_batch_run_timed", "speech_batch_run_pcm16",
     "speech_batch_stats", "speech_batch_cmvn", "speech_batch_affine", "speech_batch_add_deltas", "speech_batch_splice",
     "speech_batch_splice_subsample", "speech_batch_subsample_rows", "speech_extract_pcm16", "speech_batch_set_ids", "speech_plan_run_host", "speech_host_release",
-    "speech_set_dropin_dither", "speech_batch_synth_audio", "speech_synth_audio_host",
+    "speech_batch_cmvn_noalloc", "speech_set_dropin_dither", "speech_batch_synth_audio", "speech_synth_audio_host",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     lib.speech_batch_stats.argtypes = [vp, vp, pd, pd, C.POINTER(C.c_ulonglong), vp]; lib.speech_batch_stats.restype = i
     lib.speech_batch_cmvn.argtypes = [vp, vp, i, vp]; lib.speech_batch_cmvn.restype = i
     lib.speech_batch_affine.argtypes = [vp, vp, pd, pd, vp]; lib.speech_batch_affine.restype = i
+    lib.speech_batch_cmvn_noalloc.argtypes = [vp, vp, i, vp]; lib.speech_batch_cmvn_noalloc.restype = i
     lib.speech_synth_audio_host.argtypes = [C.c_ulonglong, C.c_ulonglong, z, C.POINTER(C.c_short)]; lib.speech_synth_audio_host.restype = i
     lib.speech_set_dropin_dither.argtypes = [C.c_ulonglong, C.c_longlong]; lib.speech_set_dropin_dither.restype = None
     lib.speech_batch_synth_audio.argtypes = [vp, vp, i, C.c_ulonglong, C.POINTER(C.c_ulonglong), vp]; lib.speech_batch_synth_audio.restype = i

@@ -297,6 +297,11 @@ class Batch:
         """per-utterance mean (and variance) normalisation, in place"""
         self._check(self._lib.speech_batch_cmvn(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), int(bool(norm_vars)), C.c_void_p(stream) if stream else None))
 
+    def cmvn_noalloc(self, Y, norm_vars=False, stream=None):
+        """cmvn through speech_batch_cmvn_noalloc: the same result from a static 4 MiB device scratch, no allocation"""
+        self._check(self._lib.speech_batch_cmvn_noalloc(self._h, _dev_ptr(Y, "Y", self.plan, self._y_end), int(bool(norm_vars)),
+                                                        C.c_void_p(stream) if stream else None))
+
     def affine(self, Y, scale, offset, stream=None):
         """y = y * scale[d] + offset[d] in place (e.g. corpus-wide CMVN from merged stats)"""
         D = self.plan.D

@@ -386,6 +386,30 @@ int post_moments(const char *fn, speech_batch *b, const void *Y, PostParams *pp,
 }
 
 
+// ---- static device scratch of speech_batch_cmvn_noalloc (include/speech_hip.h) ----
+// Per-utterance moments [nutt][2][D] in double, for callers that cannot allocate.  Each GPU holds its own copy of the array
+// at its own address: the address is asked for once per device (speech_plan_create, with that device current) and kept;
+// host code uses only that pointer, never the array's name.
+constexpr size_t SCRATCH_DOUBLES = (size_t)512 * 1024;                      // 4 MiB per GPU, held until the process ends
+static __device__ __align__(256) double scratch[SCRATCH_DOUBLES];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+std::atomic<double *> g_scratch_ptr[SCRATCH_MAX_DEVICES];
+std::mutex g_scratch_mu;
+
+// with device `dev` current
+int scratch_init(const char *fn, int dev)
+{
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) { return 0; }                // such a device simply has no no-alloc entry point
+    if (g_scratch_ptr[dev].load() != nullptr) { return 0; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev].load() != nullptr) { return 0; }
+    double *ptr = nullptr;
+    HIP_TRY(fn, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) { return fail(fn, "hipGetSymbolAddress returned a null address for the static scratch"); }
+    g_scratch_ptr[dev].store(ptr);
+    return 0;
+}
+
 int batch_run(speech_batch *b, const void *X, const short *X16, void *Y, void *stream, float *kernel_ms)
 {
     const char *fn = "speech_batch_run";
@@ -490,6 +514,7 @@ int speech_plan_create(speech_plan **out, const speech_opts *opts, int device)
     if (p->P > 256u) { delete p; return fail(fn, "lpc_order above 256 is not supported"); }
     DeviceGuard g(device);
     if (!g.ok) { delete p; return fail(fn, "cannot select device %d", device); }
+    if (scratch_init(fn, device)) { delete p; return 1; }                  // once per device: the address of the static scratch
     const int rc = (o.dtype == SPEECH_F64) ? plan_build<double>(p) : plan_build<float>(p);
     if (rc) { speech_plan_destroy(p); return 1; }
     if (!p->tuned)
@@ -719,6 +744,33 @@ int speech_batch_cmvn(speech_batch *b, void *Y, int norm_vars, void *stream)
     if (!g.ok) { return fail(fn, "cannot select device %d", b->plan->device); }
     hipStream_t s = (hipStream_t)stream;
     if (post_moments(fn, b, Y, &pp, s)) { return 1; }
+    pp.Y = Y; pp.mode = 1; pp.norm_vars = norm_vars ? 1 : 0;
+    HIP_TRY(fn, launch_post(POST_AFFINE, b->plan->o.dtype == SPEECH_F64, pp, mw, s));
+    return 0;
+}
+
+int speech_batch_cmvn_noalloc(speech_batch *b, void *Y, int norm_vars, void *stream)
+{
+    const char *fn = "speech_batch_cmvn_noalloc";
+    PostParams pp; uint32_t mw;
+    if (post_begin(fn, b, &pp, &mw)) { return 1; }
+    if (pp.nutt == 0 || b->total_frames == 0) { return 0; }
+    if (!Y) { return fail(fn, "null device pointer"); }
+    const size_t need = (size_t)pp.nutt * 2u * (size_t)pp.D;
+    if (need > SCRATCH_DOUBLES)
+    {
+        return fail(fn, "%u utterances x %d features need %zu bytes of moments; the static scratch holds %zu (use speech_batch_cmvn)",
+                    pp.nutt, pp.D, need * sizeof(double), SCRATCH_DOUBLES * sizeof(double));
+    }
+    const int dev = b->plan->device;
+    double *ptr = (dev >= 0 && dev < SCRATCH_MAX_DEVICES) ? g_scratch_ptr[dev].load() : nullptr;
+    if (!ptr) { return fail(fn, "no static scratch on device %d", dev); }
+    DeviceGuard g(dev);
+    if (!g.ok) { return fail(fn, "cannot select device %d", dev); }
+    hipStream_t s = (hipStream_t)stream;
+    // the moments pass writes every entry the affine pass reads: nothing has to start at zero
+    pp.Yin = Y; pp.mom = ptr;
+    HIP_TRY(fn, launch_post(POST_MOMENTS, b->plan->o.dtype == SPEECH_F64, pp, 0, s));
     pp.Y = Y; pp.mode = 1; pp.norm_vars = norm_vars ? 1 : 0;
     HIP_TRY(fn, launch_post(POST_AFFINE, b->plan->o.dtype == SPEECH_F64, pp, mw, s));
     return 0;
