@@ -287,6 +287,8 @@ static void usage()
     printf(fmt, "--channel=<n>", "with a .wav input: the channel to use [default=0]");
     printf(fmt, "--raw=<f32|f64|s16>", "the input is headerless samples of this type; the output is headerless too");
     printf(fmt, "--wav_scp=<file>", "list of \"<utt-id> <.wav path>\" lines instead of <file>; -o is a Kaldi archive");
+    printf(fmt, "--seed=<n>", "dither seed [default: from the clock, as the reference: a new noise draw on every run]");
+    printf(fmt, "--utt=<n>", "with --seed: the utterance number the dither generator is keyed on [default: a per-process call counter]");
     printf(fmt, "-h, --help", "display this help and exit");
     cout << "\nMakes Kaldi " << (TOOL == TOOL_SPECTROGRAM ? "spectrogram" : TOOL == TOOL_FBANK ? "mel-fbank" : TOOL == TOOL_MFCC ? "MFCC" : "PLP")
          << " features for univariate, real-valued X on an AMD MI355X (libspeech.so).\n"
@@ -300,7 +302,9 @@ static void usage()
 int main(int argc, char *argv[])
 {
     double sr = 16000.0, fl = 25.0, shft = 10.0, d = 0.1, p = 0.97, lof = 20.0, hif = 0.0, Q = 22.0, compress = 1.0 / 3.0, cep_scale = 1.0;
-    long Bi = 23, Ci = 13, channel = 0;
+    long Bi = 23, Ci = 13, channel = 0, utt = -1;
+    unsigned long long seed = 0;
+    bool have_seed = false;
     int snipe = 0, dc0 = 0, rawe = 0, amp = 0, lg = 0, usee = 0, mn0 = 0, help = 0;
     string wintype = "povey", ofile, ark_key, scp_file, wav_scp, raw_type;
     bool have_o = false, append = false, have_r = false;
@@ -313,7 +317,7 @@ int main(int argc, char *argv[])
         {"B", required_argument, nullptr, 'b'}, {"log", no_argument, nullptr, 'g'}, {"C", required_argument, nullptr, 'c'}, {"Q", required_argument, nullptr, 'q'},
         {"use_energy", no_argument, nullptr, 'x'}, {"zero_mean", no_argument, nullptr, 'm'}, {"ofile", required_argument, nullptr, 'o'},
         {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001},
-        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {"wav_scp", required_argument, nullptr, 1006}, {"raw", required_argument, nullptr, 1007}, {nullptr, 0, nullptr, 0}};
+        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {"wav_scp", required_argument, nullptr, 1006}, {"raw", required_argument, nullptr, 1007}, {"seed", required_argument, nullptr, 1008}, {"utt", required_argument, nullptr, 1009}, {nullptr, 0, nullptr, 0}};
     const char *shortopts = TOOL == TOOL_SPECTROGRAM ? "r:t:s:ed:zyp:w:mo:h" : TOOL == TOOL_FBANK ? "r:t:s:ed:zyp:w:al:u:b:gxmo:h" : "r:t:s:ed:zyp:w:l:u:b:c:q:xmo:h";
     int c, nerrs = 0;
     opterr = 0;
@@ -338,6 +342,8 @@ int main(int argc, char *argv[])
             case 1004: append = true; break;
             case 1006: wav_scp = optarg; break;
             case 1007: raw_type = optarg; if (raw_type != "f32" && raw_type != "f64" && raw_type != "s16") { ++nerrs; } break;
+            case 1008: seed = strtoull(optarg, &end, 0); have_seed = true; if (end == optarg || *end) { ++nerrs; } break;
+            case 1009: utt = strtol(optarg, &end, 10); if (end == optarg || *end || utt < 0) { ++nerrs; } break;
             case 1005: channel = strtol(optarg, &end, 10); if (end == optarg || *end || channel < 0) { ++nerrs; } break;
             default: ++nerrs; cerr << prog() << ": invalid option \"" << argv[optind - 1] << "\"" << endl; break;
         }
@@ -417,11 +423,19 @@ int main(int argc, char *argv[])
         if (Q < 0.0) { FAIL("Q must be nonnegative"); }
     }
 
+    // dither: the reference seeds its generator from the wall clock on every run (c/kaldi_fbank.c:97-101), and so does this tool
+    // unless --seed pins the noise; --utt pins the utterance number as well (speech_hip.h, speech_set_dropin_dither)
+    if (!have_seed)
+    {
+        timespec now; clock_gettime(CLOCK_REALTIME, &now);
+        seed = (unsigned long long)now.tv_sec * 1000000000ull + (unsigned long long)now.tv_nsec;
+    }
+    speech_set_dropin_dither(seed, have_seed ? (long long)utt : -1);
     auto make_opts = [&](speech_opts &o) {
         speech_opts_default(&o, TOOL == TOOL_SPECTROGRAM ? SPEECH_SPECTROGRAM : TOOL == TOOL_FBANK ? SPEECH_FBANK : TOOL == TOOL_MFCC ? SPEECH_MFCC : SPEECH_PLP);
         o.dtype = SPEECH_F32; o.sr = sr; o.frame_length = fl; o.frame_shift = shft; o.snip_edges = snipe; o.dither = d; o.dc0 = dc0; o.raw_energy = rawe;
         o.preemph = p; o.mn0 = mn0; o.amp = amp; o.lof = lof; o.hif = hif; o.B = B; o.lg = lg; o.use_energy = usee; o.C = C; o.Q = Q;
-        o.compress = compress; o.cep_scale = cep_scale; o.lpc_order = 0;
+        o.compress = compress; o.cep_scale = cep_scale; o.lpc_order = 0; o.dither_seed = seed;
         strncpy(o.win_type, wintype.c_str(), sizeof(o.win_type) - 1); o.win_type[sizeof(o.win_type) - 1] = '\0';
     };
     if (list_mode)
@@ -448,17 +462,25 @@ int main(int argc, char *argv[])
     const size_t N = i1.shape.empty() ? 1 : i1.n;
     if (N == 0) { FAIL("input (X) found to be empty"); }
 
-    // output shape: src/kaldi_mfcc.cpp:255-261 (sizes in double here, in the working precision inside the library)
-    const size_t L = (size_t)(sr * fl / 1000.0), stp = (size_t)(sr * shft / 1000.0);
-    if (stp < 1 || (snipe && L > N)) { FAIL("frame length must be < signal length if snip_edges, and frame shift at least one sample"); }
-    const size_t W = snipe ? 1u + (N - L) / stp : (N + stp / 2u) / stp;
-    size_t nfft = 1; while (nfft < L) { nfft *= 2; }
-    const size_t D = TOOL == TOOL_SPECTROGRAM ? nfft / 2 + 1 : TOOL == TOOL_FBANK ? B + (usee ? 1u : 0u) : C;
-
     const bool ark = !ark_key.empty();
     if (ark && (ark_key.find_first_of(" \t\n") != string::npos)) { FAIL("ark utterance id must not contain white space"); }
     if (!ark && (append || !scp_file.empty())) { FAIL("--append and --scp need --ark=<utt-id>"); }
     if (!scp_file.empty() && (stdo1 || !wo1)) { FAIL("--scp needs an output file (-o), not stdout"); }
+
+    // output shape: src/kaldi_mfcc.cpp:255-261.  L, stp, nfft, D and W come from the library (computed there in the working
+    // precision of the input, as the reference does), so the header written below always matches what the call fills in.
+    size_t L = 0, stp = 0, nfft = 0, D = 0, W = 0;
+    {
+        speech_opts o; make_opts(o);
+        o.dtype = i1.f64 ? SPEECH_F64 : SPEECH_F32;
+        speech_plan *probe = nullptr;
+        if (speech_plan_create(&probe, &o, 0)) { FAIL("problem during function call"); }
+        speech_plan_sizes(probe, &L, &stp, &nfft, &D, nullptr);
+        const int bad = speech_plan_num_frames(probe, N, &W);
+        speech_plan_destroy(probe);
+        if (bad) { FAIL("frame length must be < signal length if snip_edges, and frame shift at least one sample"); }
+    }
+
     ofstream ofs1;
     long long ark_off = 0;
     if (wo1 && !stdo1)

@@ -372,16 +372,18 @@ template <typename T>
 hipError_t launch_generic(const FrameParams<T> &p, hipStream_t s)
 {
     if (p.ntiles == 0) { return hipSuccess; }
-    const size_t lds = generic_lds_bytes(p.nfft, p.B, p.C, p.P, sizeof(T));
-    if (lds > 48 * 1024)   // opt in to large dynamic LDS on whichever device is current
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&generic_frames_kernel<T, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { return e; }
-    }
+    const size_t lds = generic_lds_bytes(p.nfft, p.B, p.C, p.P, sizeof(T));      // above 48 KB: opted in by generic_prepare at plan creation
     if (p.nfft <= 1024) { hipLaunchKernelGGL((generic_frames_kernel<T, 64>), dim3(p.ntiles), dim3(64), lds, s, p); }
     else { hipLaunchKernelGGL((generic_frames_kernel<T, NT>), dim3(p.ntiles), dim3(NT), lds, s, p); }
     return hipGetLastError();
+}
+
+template <typename T>
+hipError_t prepare_generic(int nfft, size_t lds)
+{
+    // the instantiation launch_generic will pick, on the current device
+    const void *k = (nfft <= 1024) ? reinterpret_cast<const void *>(&generic_frames_kernel<T, 64>) : reinterpret_cast<const void *>(&generic_frames_kernel<T, NT>);
+    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 }  // namespace
@@ -392,6 +394,14 @@ size_t generic_lds_bytes(int nfft, int B, int C, int P, size_t elem)
     size_t n = (size_t)2 * nfft + NT + (size_t)B + (size_t)(B + 2) + (size_t)4 * (P + 1) + 4 + 4;
     if (nfft <= 1024 && elem == 4) { n += (size_t)2 * nfft; }                             // twiddles and window cached by the one-wave workgroups
     return (n * elem + 15) & ~(size_t)15;
+}
+
+// Opt the generic kernel that serves (nfft, elem) in to `lds` bytes of dynamic LDS on the current device.  Called when a plan is
+// created, so that speech_batch_run itself only launches (and can be captured in a HIP graph).
+hipError_t generic_prepare(int nfft, size_t elem, size_t lds)
+{
+    if (lds <= 48u * 1024u) { return hipSuccess; }
+    return elem == 8 ? prepare_generic<double>(nfft, lds) : prepare_generic<float>(nfft, lds);
 }
 
 hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s) { return launch_generic<float>(p, s); }

@@ -74,6 +74,7 @@ struct HostPipe {
         }
         device = -1;
     }
+    ~HostPipe() { release(); }                                              // a worker thread that exits gives its staging back
 };
 
 thread_local HostPipe g_pipe;

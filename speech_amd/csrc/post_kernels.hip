@@ -258,6 +258,14 @@ hipError_t launch_reduce_rows(const double *in, double *out, size_t n, int cols,
     return hipGetLastError();
 }
 
+hipError_t post_prepare(bool f64, int D)
+{
+    const size_t lds = (size_t)2 * (size_t)D * (f64 ? 8u : 4u);
+    if (lds <= 48u * 1024u) { return hipSuccess; }
+    const void *k = f64 ? reinterpret_cast<const void *>(&utt_affine_kernel<double>) : reinterpret_cast<const void *>(&utt_affine_kernel<float>);
+    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_frames, hipStream_t s)
 {
     if (p.nutt == 0) { return hipSuccess; }

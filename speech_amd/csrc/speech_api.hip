@@ -521,6 +521,12 @@ int speech_plan_create(speech_plan **out, const speech_opts *opts, int device)
     {
         const size_t lds = generic_lds_bytes((int)sz.nfft, (int)o.B, (int)o.C, (int)p->P, o.dtype == SPEECH_F64 ? 8 : 4);
         if (lds > 160u * 1024u) { speech_plan_destroy(p); return fail(fn, "frame of %zu samples does not fit in LDS (%zu bytes needed)", sz.L, lds); }
+        const hipError_t e = generic_prepare((int)sz.nfft, o.dtype == SPEECH_F64 ? 8u : 4u, lds);
+        if (e != hipSuccess) { speech_plan_destroy(p); return fail(fn, "cannot reserve %zu bytes of LDS for the frame kernel: %s", lds, hipGetErrorString(e)); }
+    }
+    {
+        const hipError_t e = post_prepare(o.dtype == SPEECH_F64, (int)sz.D);     // mn0 / cmvn / affine passes of this plan's batches
+        if (e != hipSuccess) { speech_plan_destroy(p); return fail(fn, "cannot reserve LDS for the normalisation pass: %s", hipGetErrorString(e)); }
     }
     *out = p;
     return 0;

@@ -192,6 +192,8 @@ hipError_t launch_synth(void *X, int elem, const UttDesc *utts, const unsigned l
 hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s);
 hipError_t launch_generic_f64(const FrameParams<double> &p, hipStream_t s);
 size_t generic_lds_bytes(int nfft, int B, int C, int P, size_t elem);
+hipError_t generic_prepare(int nfft, size_t elem, size_t lds);
+hipError_t post_prepare(bool f64, int D);                                  // the affine pass keeps 2 D scale / offset values in LDS
 
 constexpr int GENERIC_TILE_FRAMES = 8;
 constexpr int GENERIC_MAX_NFFT = 8192;

@@ -96,10 +96,18 @@ def test_cli_matches_library(tmp_path):
     pl = np.load(tmp_path / "p.npy")
     ref = api.kaldi_plp(x.astype(np.float64))
     assert pl.dtype == np.float64 and pl.shape == ref.shape[::-1] and np.isfortran(pl) and np.array_equal(pl.T, ref)
-    # default dither 0.1 is on and seeded: runs, differs from -d0, reproducible
+    # default dither 0.1 is on: seeded from the clock as in the reference (c/kaldi_fbank.c:97-101), so two runs differ;
+    # --seed pins the noise (and --utt the utterance number), and then two runs agree bit for bit
     a = run("kaldi_mfcc", "-e", str(xf), "-o", str(tmp_path / "a.npy")); b = run("kaldi_mfcc", "-e", str(xf), "-o", str(tmp_path / "b.npy"))
     assert a.returncode == 0 and b.returncode == 0
-    assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))
+    ya, yb = np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy")
+    assert ya.shape == yb.shape and not np.array_equal(ya, yb) and np.abs(ya - yb).max() < 2.0
+    outs = []
+    for name, extra in (("c", ("--seed=7",)), ("d", ("--seed=7",)), ("e", ("--seed=7", "--utt=3")), ("f", ("--seed=8",))):
+        r = run("kaldi_mfcc", "-e", *extra, str(xf), "-o", str(tmp_path / (name + ".npy")))
+        assert r.returncode == 0, r.stderr
+        outs.append(np.load(tmp_path / (name + ".npy")))
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2]) and not np.array_equal(outs[0], outs[3])
 
 
 def read_ark(path):
@@ -269,11 +277,12 @@ def test_wav_scp_to_archive(tmp_path):
         assert np.array_equal(m, api.kaldi_mfcc(x.astype(np.float32), B=40, C=20)), k
     by_scp = list(ark.read_scp(str(scp)))                     # follows "<utt-id> <ark>:<offset>"
     assert [k for k, _ in by_scp] == [k for k, _, _ in got] and all(np.array_equal(a[1], b[2]) for a, b in zip(by_scp, got))
-    # --append adds to the archive with correct offsets; default hif = Nyquist of the files' rate; dither (default 0.1) reproducible
-    r = run("kaldi_fbank", "-g", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f.ark"))
-    r2 = run("kaldi_fbank", "-g", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f2.ark"))
-    assert r.returncode == 0 and r2.returncode == 0, r.stderr
-    assert (tmp_path / "f.ark").read_bytes() == (tmp_path / "f2.ark").read_bytes()
+    # --append adds to the archive with correct offsets; default hif = Nyquist of the files' rate; dither (default 0.1) reproducible under --seed
+    r = run("kaldi_fbank", "-g", "--seed=11", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f.ark"))
+    r2 = run("kaldi_fbank", "-g", "--seed=11", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f2.ark"))
+    r3 = run("kaldi_fbank", "-g", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f3.ark"))
+    assert r.returncode == 0 and r2.returncode == 0 and r3.returncode == 0, r.stderr
+    assert (tmp_path / "f.ark").read_bytes() == (tmp_path / "f2.ark").read_bytes() != (tmp_path / "f3.ark").read_bytes()
     r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "-b", "40", "-c", "20", "--append", "--wav_scp=%s" % lst, "-o", str(out), "--scp=%s" % scp)
     assert r.returncode == 0, r.stderr
     again = list(ark.read_ark(str(out)))

@@ -600,3 +600,77 @@ def test_pcm16_input_equals_float_input(kind, o, dtype):
         oo = {k: v for k, v in o.items() if k != "force_generic"}
         ok, msg = _parity(kind, oo, xs[0], got)
         assert ok, msg
+
+
+def test_generic_plans_with_more_than_48_KB_of_LDS():
+    """plans whose frame kernel (or normalisation pass) needs more than the default 48 KB of dynamic LDS: the opt-in belongs to
+    plan creation and to the kernel instantiation that is launched (one-wave workgroups up to 1024-point frames)"""
+    import torch
+    x = signals.utterance(3000, 4242, dtype=np.float64)
+    # float64, 512-point frames, 3000 mel bins: 58 KB in the one-wave instantiation
+    o = dict(B=3000, lg=0)
+    got = api.kaldi_fbank(x, **o)
+    rc, ref = O.run("fbank", x, single=False, **o)
+    assert rc == 0 and max_err("fbank", o, got, ref) <= 1e-9 * max(1.0, float(np.abs(ref).max()))
+    # float64 spectrogram of 8192-point frames with mn0: the affine pass keeps 2 x 4097 doubles in LDS (65.5 KB); first run under capture
+    xl = signals.utterance(20000, 4243, sr=48000.0, dtype=np.float64)
+    plan = api.Plan("spectrogram", dtype="f64", sr=48000.0, fl=100.0, fs=40.0, mn0=1)
+    assert plan.D == 4097 and not plan.tuned
+    b = api.Batch(plan, [xl.size])
+    X = torch.from_numpy(xl).cuda()
+    Y = torch.zeros(b.total_out, device="cuda", dtype=torch.float64)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            b.run(X, Y, stream=torch.cuda.current_stream().cuda_stream)
+    graph.replay()
+    torch.cuda.synchronize()
+    rc, ref = O.run("spectrogram", xl, single=False, sr=48000.0, fl=100.0, fs=40.0, mn0=1)
+    assert rc == 0 and np.abs(Y.cpu().numpy().reshape(ref.shape) - ref).max() <= 1e-9
+
+
+def test_dropin_calls_with_many_option_sets_do_not_grow_device_memory():
+    """the drop-in plan cache holds 16 plans; evicted plans are destroyed when their last call returns (shared_ptr), so 200
+    distinct option sets leave the device's free memory where 20 did"""
+    import torch
+    x = signals.utterance(3000, 77)
+
+    def sweep(n0, n1):
+        for i in range(n0, n1):
+            api.kaldi_mfcc(x, B=23 + i % 60, C=13, lof=20.0 + i)
+            api.kaldi_fbank(x.astype(np.float64), B=20 + i % 50, hif=7000.0 + i)
+
+    sweep(0, 20)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    sweep(20, 220)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] <= 8 * 2 ** 20
+
+
+def test_dithered_dropin_calls_draw_fresh_noise_unless_pinned():
+    """the reference seeds its dither from the wall clock per call (c/kaldi_fbank.c:97-101); here successive dithered drop-in
+    calls take successive utterance numbers, and speech_set_dropin_dither pins the number for reproducible runs"""
+    from speech_amd import _lib
+    lib = _lib.load()
+    x = signals.utterance(4000, 5)
+    lib.speech_set_dropin_dither(0x5EED2026, -1)
+    a, b = api.kaldi_mfcc(x, dither=1.0), api.kaldi_mfcc(x, dither=1.0)
+    assert not np.array_equal(a, b)
+    lib.speech_set_dropin_dither(0x5EED2026, -1)                           # restarts the counter
+    assert np.array_equal(api.kaldi_mfcc(x, dither=1.0), a)
+    lib.speech_set_dropin_dither(99, 7)
+    c, d = api.kaldi_mfcc(x, dither=1.0), api.kaldi_mfcc(x, dither=1.0)
+    assert np.array_equal(c, d) and not np.array_equal(c, a)
+    # the pinned number is the batch ABI's utterance id under the same seed
+    import torch
+    plan = api.Plan("mfcc", dither=1.0, dither_seed=99)
+    bt = api.Batch(plan, [x.size])
+    bt.set_ids([7])
+    Y = torch.zeros(bt.total_out, device="cuda")
+    bt.run(torch.from_numpy(x).cuda(), Y)
+    torch.cuda.synchronize()
+    assert np.array_equal(Y.cpu().numpy().reshape(c.shape), c)
+    lib.speech_set_dropin_dither(0x5EED2026, -1)
+    assert np.array_equal(api.kaldi_mfcc(x), api.kaldi_mfcc(x))           # dither off: nothing changes
