@@ -35,7 +35,7 @@ namespace speech {
 
 constexpr int MAX_MTILES = 8;            // mel tiles of up to 16 columns (B <= 128), balanced over the waves; cepstral tiles of 16 (C <= 96)
 
-struct FastGeom { bool ok, pair, wide; int fw, nz, tile; size_t span, ws, lds; };      // launch geometry of a plan, fast_geom()
+struct FastGeom { bool ok, pair, wide; int fw, nz, tile; size_t span, ws, lds, m2; };  // m2: floats of mat2 staged in LDS (0: read from global)      // launch geometry of a plan, fast_geom()
 
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[8][16] complex
@@ -57,6 +57,7 @@ constexpr int MW = 8;                   // waves per workgroup, mel kinds: with 
                                         // per mel tile, i.e. a job for every wave, and half as many workgroup barriers per frame
 constexpr int NTM = 64 * MW;            // threads per workgroup, mel kinds
 
+constexpr int PLP_TAIL_FRAMES = 64;     // plp: frames per workgroup (sub-tiles of MW x frames-per-wave); the serial tail runs once, one lane per frame
 constexpr int TILE_SPEC = 64;  // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
 constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
 constexpr int TR_WAVE_C = 2048;         // floats of a wave's slice when the transposition image is complex (spectrogram kernel)
@@ -89,6 +90,7 @@ struct FastParams {
     // mel kinds
     const float *melw, *mat2, *aux;
     int B, C, MP, Cp, K2, ntile_m, ntile_c;
+    int m2;                             // floats of mat2 staged in LDS between the tables and the slices (0: not staged)
     int amp, lg, use_energy, compress_mode;
     float compress;
     int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES], mel_first[MAX_MTILES], mel_cnt[MAX_MTILES];
@@ -226,6 +228,13 @@ __device__ __forceinline__ float pos_log(float v)
     const float m = __builtin_amdgcn_frexp_mantf(v);
     const float e = (float)__builtin_amdgcn_frexp_expf(v);
     return fmaf(e, 0.69314718055994530942f, __log2f(m) * 0.69314718055994530942f);
+}
+
+// 1 / x to 1 ulp: v_rcp_f32 and one Newton step (3 instructions; an IEEE division is 10)
+__device__ __forceinline__ float fast_rcp(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
 
 __device__ __forceinline__ float floor_log(float v) { return pos_log(fmaxf(v, FLT_EPSILON)); }

@@ -9,7 +9,12 @@
 
 namespace speech {
 
-static int mel_pitch(int cols) { return 32 * ((cols + 31) / 32) + 2; }              // = 2 (mod 32): the MFMA A-operand reads are conflict-free
+// Row pitch of the mel tile: twice an odd number >= cols, which makes the MFMA A-operand reads conflict-free (a k-step's
+// 32 lanes read rows 0..15 at two consecutive columns: banks 2 h r + c with h odd are distinct for r < 16, c < 2)
+static int mel_pitch(int cols) { const int h = (cols + 1) / 2; return 2 * (h | 1); }
+
+// LDS a workgroup may use if three are to fit on a CU (160 KB in granules of 1280 bytes)
+constexpr size_t LDS_3_PER_CU = 42u * 1280u;
 
 // Launch geometry of a plan on the tuned kernels: 512-point frames (257..512 samples), or 256-point frames (129..256) two
 // per transform (`pair`: 8 frames per wave).
@@ -43,15 +48,21 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
         if (P != 12u) { return g; }                                         // the in-register Levinson-Durbin is built for order 12
         D = o.C; cols = (o.B + 2u + 3u) & ~(size_t)3;
     }
-    g.tile = MW * g.fw;
-    const size_t T = (size_t)g.tile;
+    const size_t T = (size_t)MW * (size_t)g.fw;                             // frames per sub-tile: one pass of the workgroup
+    const size_t nsub = (o.kind == SPEECH_PLP) ? (size_t)PLP_TAIL_FRAMES / T : 1u;      // plp: sub-tiles per workgroup (fast_mel.hip)
+    g.tile = (int)(T * nsub);
     g.ws = std::max(g.span, g.wide ? (T * PPW + MW - 1) / MW : (g.pair ? (T * PP2 + MW - 1) / MW : (size_t)TR_WAVE));     // the slices together hold the power tile
-    // behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile; the mfcc / plp output and
-    // autocorrelation tiles reuse the power tile's place
-    const size_t extra = T + (o.kind == SPEECH_FBANK ? ((T * D + 3u) & ~(size_t)3) : T * (size_t)mel_pitch((int)cols));
-    if (((T * D + 3u) & ~(size_t)3) + T * 17u > (size_t)MW * g.ws) { return g; }
+    // behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile | plp: autocorrelations; the mfcc / plp
+    // output tile reuses the power tile's place
+    const size_t extra = T * nsub + (o.kind == SPEECH_FBANK ? ((T * D + 3u) & ~(size_t)3) : T * (size_t)mel_pitch((int)cols))
+                         + (o.kind == SPEECH_PLP ? T * nsub * 17u : 0u);
+    if (T * nsub * D > (size_t)MW * g.ws) { return g; }
     g.lds = (tabf + MW * g.ws + extra) * sizeof(float);
     g.ok = g.lds <= 64u * 1024u;
+    // the second contraction's matrix (mfcc: lifter x DCT, K2 x Cp; plp: IDFT bases, K2 x 16) rides in LDS behind the
+    // tables when that does not cost a resident workgroup; otherwise the kernel reads it from global memory (L2)
+    const size_t m2 = (o.kind == SPEECH_MFCC) ? cols * 16u * ((o.C + 15u) / 16u) : (o.kind == SPEECH_PLP ? cols * 16u : 0u);
+    if (g.ok && m2 > 0u && g.lds + m2 * sizeof(float) <= LDS_3_PER_CU) { g.m2 = m2; g.lds += m2 * sizeof(float); }
     return g;
 }
 
@@ -225,7 +236,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, hipStr
     p.X = fp.X; p.X16 = fp.X16; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
     const FastGeom &g = t->geom;
-    p.span = (int)g.span; p.ws = (int)g.ws;
+    p.span = (int)g.span; p.ws = (int)g.ws; p.m2 = (int)g.m2;
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.do_dither = fp.do_dither; p.dither = fp.dither; p.seed = fp.seed;

@@ -53,6 +53,52 @@ __device__ __forceinline__ f32x4 mfma_tile4(const float *arow, const __amdgpu_bu
     return acc0 + acc1;
 }
 
+// The same contractions with the B operand (weights) fetched AHEAD: all of a job's first KP k-steps are requested in one
+// run of buffer loads, issued before the workgroup barrier that precedes the contraction, so the L2 latency of the weights
+// is spent waiting at that barrier instead of once per four k-steps inside the loop.  Loads beyond the tile's k-steps fall
+// outside the descriptor's range and return 0 without touching memory.  During these phases the FFT's 32 registers of
+// samples are dead, so the KP registers cost no occupancy.
+constexpr int KPRE = 24;
+
+template <int KP>
+__device__ __forceinline__ void weights_issue(float (&b)[KP], const __amdgpu_buffer_rsrc_t rb, const int voff, const int stepbytes)
+{
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { b[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, stepbytes * j, 0)); }
+}
+
+// k-steps 0 .. min(ksteps, KP) - 1 from the prefetched weights, in groups of G (ksteps a multiple of G); the A operands of the
+// next group are read from LDS while the current group's MFMAs run
+template <int KP, int G>
+__device__ __forceinline__ f32x4 mfma_tile_pre(const float *arow, const float (&b)[KP], const int ksteps)
+{
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ksteps <= 0) { return acc0; }
+    float a[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { a[g] = arow[4 * g]; }
+#pragma unroll
+    for (int s = 0; s < KP; s += G)
+    {
+        if (s < ksteps)
+        {
+            const int sn = min(s + G, ksteps - G);                          // the last group reloads itself (harmless)
+            float an[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { an[g] = arow[4 * (sn + g)]; }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+            {
+                if (((s + g) & 1) == 0) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g], b[s + g], acc0, 0, 0, 0); }
+                else { acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g], b[s + g], acc1, 0, 0, 0); }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) { a[g] = an[g]; }
+        }
+    }
+    return acc0 + acc1;
+}
+
 // fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
 // Levinson-Durbin and the cepstral recursion stay in registers).
 // PAIR (256-point plans): 8 frames per wave as 4 pairs (frame_power_pair), 64 frames per tile, a 64 x 130
@@ -67,30 +113,46 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     constexpr int TILEK = MW * FWK;                                         // frames per workgroup
     constexpr int RTK = TILEK / 16;                                         // 16-frame row tiles
     constexpr int PPK = WIDE ? PPW : (PAIR ? PP2 : PP);                     // pitch of the power tile
+    // plp: the workgroup walks NSUB sub-tiles of TILEK frames through the FFT, mel and IDFT phases and only then runs the
+    // serial tail (Levinson-Durbin, one lane per frame) once, on 64 frames: one full wave instead of a half or quarter one
+    // per 32 or 16 frames, and one barrier pair less per sub-tile
+    constexpr int NSUB = (KIND == SPEECH_PLP) ? PLP_TAIL_FRAMES / TILEK : 1;
     constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;                   // floats of tables in front of the slices
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *s_tab = smem;
-    float *s_aud = smem + TABK + wv * p.ws;                                 // the wave's slice: audio, then transposition image
+    float *s_m2 = smem + TABK;                                              // mat2, when staged (p.m2 floats)
+    float *s_sl = s_m2 + p.m2;                                              // the waves' slices
+    float *s_aud = s_sl + wv * p.ws;                                 // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
     // after the FFTs the slices are dead and hold the TILEK x PPK power tile
-    float *s_pow = smem + TABK;
+    float *s_pow = s_sl;
     // private region behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile.  The mfcc / plp output
     // tile (and plp's autocorrelations) are written after the power tile is dead and reuse its place.
-    float *s_e = smem + TABK + MW * p.ws;
+    float *s_e = s_sl + MW * p.ws;
     float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILEK : s_pow;
-    float *s_mel = s_e + TILEK;
-    float *s_ac = s_out + ((TILEK * p.D + 3) & ~3);
+    float *s_mel = s_e + NSUB * TILEK;
+    float *s_ac = s_mel + TILEK * p.MP;                                     // plp: [NSUB * TILEK][17] autocorrelations, kept across the sub-tiles
     for (int i = tid; i < TABK; i += NTM) { s_tab[i] = p.tab[i]; }
+    for (int i = tid; i < p.m2; i += NTM) { s_m2[i] = p.mat2[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
-    const int fq = wv * FWK;
-    const int nfr = min((int)tile.nframes - fq, FWK);
+    const int fq = wv * FWK;                                                // the wave's first frame within the sub-tile
+    for (int sub = 0; sub < NSUB; ++sub)
+    {
+    const int fbase = sub * TILEK;                                          // the sub-tile's first frame within the tile
+    // what the body derives from the lane number and reads from the tables (twiddles, window: some 70 registers' worth) is
+    // loop-invariant; hoisted out of the sub-tile loop it would cost a resident workgroup per CU, so both are made opaque here
+    if (NSUB > 1) { asm volatile("" : "+v"(lane)); }
+    const float *s_tab_l = (NSUB > 1) ? s_tab + opaque_zero() : s_tab;
+    if (sub > 0 && fbase >= (int)tile.nframes) { break; }                   // (uniform) a short last tile
+    const int nfr = min((int)tile.nframes - fbase - fq, FWK);
     if (nfr > 0)
     {
-        const long long w0 = (long long)tile.frame0 + fq;
+        const long long w0 = (long long)tile.frame0 + fbase + fq;
         const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
         load_span(s_aud, p.X + utt.x_off, p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
     }
@@ -103,28 +165,43 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     {
         // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds; its row is never stored)
         const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)),
-                                                                  (unsigned long long)((long long)tile.frame0 + fq + (lane >> 5))) : 0ull;
-        frame_power_wide<NZ, true, DITHER>(s_aud + (lane >> 5) * p.stp, s_tab, s_tr, lane, p, dkey, pa, pb, rawe);
+                                                                  (unsigned long long)((long long)tile.frame0 + fbase + fq + (lane >> 5))) : 0ull;
+        frame_power_wide<NZ, true, DITHER>(s_aud + (lane >> 5) * p.stp, s_tab_l, s_tr, lane, p, dkey, pa, pb, rawe);
     }
     else if (nfr > 0 && PAIR)
     {
         // lanes 16 f .. 16 f + 15: frames fq + 2 f (A) and fq + 2 f + 1 (B; a missing B repeats A, its row is never stored)
         const unsigned long long ku = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.uid << 32)) : 0ull;
-        const unsigned long long wa = (unsigned long long)((long long)tile.frame0 + fq + 2 * f);
+        const unsigned long long wa = (unsigned long long)((long long)tile.frame0 + fbase + fq + 2 * f);
         const unsigned long long ka = DITHER ? dither_frame_key(ku, wa) : 0ull, kb = DITHER ? dither_frame_key(ku, wa + 1) : 0ull;
-        frame_power_pair<NZ, true, DITHER>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab, s_tr, lane, p, ka, kb, pa, pb, rawe2);
+        frame_power_pair<NZ, true, DITHER>(s_aud + 2 * f * p.stp, (2 * f + 1 < nfr) ? p.stp : 0, s_tab_l, s_tr, lane, p, ka, kb, pa, pb, rawe2);
     }
     else if (nfr > 0)
     {
         const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)),
-                                                                  (unsigned long long)((long long)tile.frame0 + fq + f)) : 0ull;
-        frame_power<NZ, true, DITHER>(s_aud + f * p.stp, s_tab, s_tr, lane, p, dkey, pa, pb, rawe);
+                                                                  (unsigned long long)((long long)tile.frame0 + fbase + fq + f)) : 0ull;
+        frame_power<NZ, true, DITHER>(s_aud + f * p.stp, s_tab_l, s_tr, lane, p, dkey, pa, pb, rawe);
     }
     else
     {
 #pragma unroll
         for (int i = 0; i < 9; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
     }
+    // weights of the wave's first mel job and of its first DCT / IDFT job: requested now, used after the barriers below
+    // (what the contractions derive from the lane number and from the plan's sizes must not be computed at the top of the
+    // kernel and carried through the FFT -- that spills; hence the opaque copies)
+    int lane_m = lane, ks2 = p.K2 >> 2;                                     // ks2: k-steps of the second contraction
+    asm volatile("" : "+v"(lane_m), "+s"(ks2));
+    const int fr0 = (lane_m >> 4) * 4, col = lane_m & 15;
+    const int njob_m = RTK * p.ntile_m;
+    const int njob_2 = (KIND == SPEECH_MFCC) ? RTK * p.ntile_c : ((KIND == SPEECH_PLP) ? RTK : 0);
+    float wpre[KPRE];
+    {
+        const int t0 = (wv < njob_m) ? wv / RTK : 0;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t0]), 0, (wv < njob_m) ? 256 * p.mel_ksteps[t0] : 0, BUF_FLAGS);
+        weights_issue(wpre, rb, lane_m * 4, 256);
+    }
+
     // The power tile takes the slices' place.  When a slice is exactly as long as the wave's rows of the tile (the usual
     // case: ws = FWK * PPK), a wave's rows lie in its own slice and it only has to be done with its own transposition image.
     if (p.ws != FWK * PPK) { __syncthreads(); } else { wave_sync(); }
@@ -149,7 +226,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
             pr[hh ? 256 - k : k] = pa[k1];
             pr[hh ? 256 + k : 512 - k] = pb[k1];
         }
-        if (k2 == 0 && hh == 0) { pr[128] = pa[8]; pr[384] = pb[8]; pr[513] = 0.0f; s_e[fq + (lane >> 5)] = rawe; }
+        if (k2 == 0 && hh == 0) { pr[128] = pa[8]; pr[384] = pb[8]; pr[513] = 0.0f; s_e[fbase + fq + (lane >> 5)] = rawe; }
     }
     else if (PAIR)
     {
@@ -169,7 +246,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
         if (k2 == 0)
         {
             pra[128] = pa[8]; prb[128] = pb[8]; pra[129] = 0.0f; prb[129] = 0.0f;
-            s_e[fq + 2 * f] = rawe2.x; s_e[fq + 2 * f + 1] = rawe2.y;
+            s_e[fbase + fq + 2 * f] = rawe2.x; s_e[fbase + fq + 2 * f + 1] = rawe2.y;
         }
     }
     else
@@ -186,19 +263,30 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
             pr[k2 + 16 * k1] = pa[k1];
             pr[NC - k2 - 16 * k1] = pb[k1];
         }
-        if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fq + f] = rawe; }       // column 257: the zero a padded k-loop may touch
+        if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fbase + fq + f] = rawe; }       // column 257: the zero a padded k-loop may touch
     }
     __syncthreads();
     if (p.ablate & 32) { if (s_pow[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
 
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
     const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
-    const int fr0 = (lane >> 4) * 4, col = lane & 15;
-    for (int job = wv; job < RTK * p.ntile_m; job += MW)
+    for (int job = wv; job < njob_m; job += MW)
     {
         const int t = job / RTK, rt = job - t * RTK;                          // mel tile, 16-frame row tile
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * p.mel_ksteps[t], BUF_FLAGS);
-        const f32x4 acc = mfma_tile4(s_pow + (16 * rt + col) * PPK + p.mel_kbeg[t] + (lane >> 4), rb, lane * 4, p.mel_ksteps[t]);
+        const int ks = p.mel_ksteps[t];
+        const float *arow = s_pow + (16 * rt + col) * PPK + p.mel_kbeg[t] + (lane_m >> 4);
+        f32x4 acc = mfma_tile_pre<KPRE, 4>(arow, wpre, ks);
+        if (ks > KPRE)                                                      // a tile of few, wide filters: the rest of its k-steps in the loop form
+        {
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * ks, BUF_FLAGS);
+            acc += mfma_tile4(arow + 4 * KPRE, rb, lane_m * 4 + 256 * KPRE, ks - KPRE);
+        }
+        if (job + MW < njob_m)                                              // the wave's next job: its weights travel during this one's epilogue
+        {
+            const int tn = (job + MW) / RTK;
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[tn]), 0, 256 * p.mel_ksteps[tn], BUF_FLAGS);
+            weights_issue(wpre, rb, lane_m * 4, 256);
+        }
         const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
         const bool live = col < p.mel_cnt[t];
 #pragma unroll
@@ -236,10 +324,12 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (KIND == SPEECH_MFCC)
     {
         // DCT-II x lifter as a second contraction (c/kaldi_mfcc.c:323-333); the last-cepstrum quirk is a duplicated column
-        for (int job = wv; job < RTK * p.ntile_c; job += MW)
+        for (int job = wv; job < njob_2; job += MW)
         {
             const int t = job / RTK, rt = job - t * RTK;
-            const f32x4 acc = mfma_tile(s_mel + (16 * rt + col) * p.MP + (lane >> 4), p.mat2 + (lane >> 4) * p.Cp + 16 * t + col, 4 * p.Cp, p.K2 >> 2);
+            const float *arow = s_mel + (16 * rt + col) * p.MP + (lane_m >> 4);
+            const int boff = (lane_m >> 4) * p.Cp + 16 * t + col;
+            const f32x4 acc = p.m2 ? mfma_tile(arow, s_m2 + boff, 4 * p.Cp, ks2) : mfma_tile(arow, p.mat2 + boff, 4 * p.Cp, ks2);
             const int c = 16 * t + col;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -257,12 +347,17 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
         // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames
         if (wv < RTK)
         {
-            const f32x4 acc = mfma_tile(s_mel + (16 * wv + col) * p.MP + (lane >> 4), p.mat2 + lane, 64, p.K2 >> 2);
+            const float *arow = s_mel + (16 * wv + col) * p.MP + (lane_m >> 4);
+            const f32x4 acc = p.m2 ? mfma_tile(arow, s_m2 + lane_m, 64, ks2) : mfma_tile(arow, p.mat2 + lane_m, 64, ks2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s_ac[(16 * wv + fr0 + r) * 17 + col] = acc[r]; }
+            for (int r = 0; r < 4; ++r) { s_ac[(fbase + 16 * wv + fr0 + r) * 17 + col] = acc[r]; }
         }
+    }
+    }   // sub-tiles
+    if (KIND == SPEECH_PLP)
+    {
         __syncthreads();
-        if (tid < TILEK)
+        if (tid < NSUB * TILEK)
         {
             // one lane per frame: Levinson-Durbin with Kaldi's 1 - k^2 >= 1e-5 guard, LPC -> cepstrum, lifter
             // (reference intent c/kaldi_plp.c:206,380-403)
@@ -275,7 +370,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
                 float ki = r[i + 1];
 #pragma unroll
                 for (int j = 0; j < i; ++j) { ki += a[j] * r[i - j]; }
-                ki = ki / E;
+                ki *= fast_rcp(E);
                 float c = 1.0f - ki * ki;
                 c = (c < 1.0e-5f) ? 1.0e-5f : c;
                 E *= c;
@@ -291,7 +386,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
                 float sum = 0.0f;
 #pragma unroll
                 for (int j = 0; j < i; ++j) { sum += (float)(i - j) * a[j] * cep[i - j - 1]; }
-                cep[i] = -a[i] - sum / (float)(i + 1);
+                cep[i] = -a[i] - sum * (1.0f / (float)(i + 1));
             }
             const float *lift = p.aux + p.B;
             float *y = s_out + tid * p.C;
