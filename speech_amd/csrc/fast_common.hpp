@@ -272,17 +272,32 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, const s
     if (s0 >= 0 && s0 + need <= N)
     {
         const int nit = (need + 63) >> 6;
-        // no per-lane bound: the slice is a whole number of 64-float rows (a guarded store here serialises the loads:
-        // 0.78 vs 0.57 ms on the mfcc workload), loads past `need` return 0
+        // Sixteen rows of 64 samples are requested back to back and only then parked in LDS, so a quad's audio costs one
+        // memory latency, not one per row (a loop of load - wait - store pairs measured 7 latencies for the usual 14 rows).
+        // No per-lane bound: the slice is a whole number of 64-float rows, loads past `need` return 0 (range check).
         if (xu16)
         {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu16 + s0), 0, need * 2, BUF_FLAGS);
-            for (int j = 0; j < nit; ++j) { s_aud[lane + 64 * j] = (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, j * 128, 0); }
+            for (int c = 0; c < nit; c += 16)
+            {
+                unsigned short v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v[j] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, (c + j) * 128, 0); }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { if (c + j < nit) { s_aud[lane + 64 * (c + j)] = (float)(short)v[j]; } }
+            }
         }
         else
         {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
-            for (int j = 0; j < nit; ++j) { s_aud[lane + 64 * j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, j * 256, 0)); }
+            for (int c = 0; c < nit; c += 16)
+            {
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, (c + j) * 256, 0)); }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { if (c + j < nit) { s_aud[lane + 64 * (c + j)] = v[j]; } }
+            }
         }
     }
     else

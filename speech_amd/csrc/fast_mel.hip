@@ -135,8 +135,9 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILEK : s_pow;
     float *s_mel = s_e + NSUB * TILEK;
     float *s_ac = s_mel + TILEK * p.MP;                                     // plp: [NSUB * TILEK][17] autocorrelations, kept across the sub-tiles
-    for (int i = tid; i < TABK; i += NTM) { s_tab[i] = p.tab[i]; }
-    for (int i = tid; i < p.m2; i += NTM) { s_m2[i] = p.mat2[i]; }
+    // tables (and the staged matrix) in 16-byte units: one load per thread in flight instead of a loop of load - wait - store
+    for (int i = tid; i < TABK / 4; i += NTM) { reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(p.tab)[i]; }
+    for (int i = tid; i < p.m2 / 4; i += NTM) { reinterpret_cast<float4 *>(s_m2)[i] = reinterpret_cast<const float4 *>(p.mat2)[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];

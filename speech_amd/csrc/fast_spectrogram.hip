@@ -20,7 +20,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     float *s_tab = smem;
     float *s_aud = smem + TABK + wv * p.ws;                                 // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
-    for (int i = tid; i < TABK; i += NT) { s_tab[i] = p.tab[i]; }
+    for (int i = tid; i < TABK / 4; i += NT) { reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(p.tab)[i]; }
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
