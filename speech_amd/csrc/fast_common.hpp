@@ -85,7 +85,7 @@ struct FastParams {
     int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
     float dither;
     unsigned long long seed;
-    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads (spectrogram kernel), 4 = mel kinds stop after the FFT, 8 = stores land in a 2 MB (L2-resident) window, 16 = every utterance reads utterance 0's audio (spectrogram kernel), 32 / 64 = mel kinds stop after the power tile / after the mel contraction
+    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads, 4 = mel kinds stop after the FFT, 8 = stores land in a 2 MB (L2-resident) window, 16 = every utterance reads utterance 0's audio, 32 / 64 = mel kinds stop after the power tile / after the mel contraction
     const float *tab;
     // mel kinds
     const float *melw, *mat2, *aux;
