@@ -345,22 +345,35 @@ __device__ __forceinline__ void fft256(f2 (&z)[16], const float *s_tab, float *s
     if (HALF)
     {
         // real parts then imaginary parts (a 1 KB image per frame keeps 7 workgroups on a CU): element (k2, n) lives at
-        // 16 k2 + 4 ((n>>2) ^ (k2>>2)) + (n&3), which makes the b32 writes and the b128 reads conflict-free
+        // 16 (k2 ^ (f & 1)) + 4 ((n>>2) ^ (k2>>2)) + (n&3), which makes the b32 writes and the b128 reads conflict-free: the
+        // swizzle spreads a frame's 16 lanes over 16 banks, and the row flip of the odd frames puts them on the other 16
+        // (a b32 access is served 32 lanes = two frames at a time; 256 floats per image alone left both on the same banks:
+        // 64 conflict cycles per quad, measured with tools/lds_by_phase.sh)
         float *trf = s_tr + f * 256;
+        const int fx = (f & 1) << 4;
+        float *trf_e = trf + fx, *trf_o = trf - fx;                         // rows kk ^ 1 of the odd frames: + 16 floats for even kk, - 16 for odd kk
         int woff[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { woff[c] = (((n1 >> 2) ^ c) << 2) + (n1 & 3); }
-        const float *rrow = trf + k2 * 16;
+        const float *rrow = trf + ((k2 * 16) ^ fx);
         const int rq = k2 >> 2;
         float4 rr[4];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].x; }
+        for (int c = 0; c < 4; ++c)                                          // rows 4c, 4c+2 | 4c+1, 4c+3: each pair one ds_write2_b32
+        {
+            trf_e[(4 * c) * 16 + woff[c]] = z[P16(4 * c)].x; trf_e[(4 * c + 2) * 16 + woff[c]] = z[P16(4 * c + 2)].x;
+            trf_o[(4 * c + 1) * 16 + woff[c]] = z[P16(4 * c + 1)].x; trf_o[(4 * c + 3) * 16 + woff[c]] = z[P16(4 * c + 3)].x;
+        }
         wave_sync();
 #pragma unroll
         for (int q = 0; q < 4; ++q) { rr[q] = *reinterpret_cast<const float4 *>(rrow + ((q ^ rq) << 2)); }
         wave_sync();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) { trf[kk * 16 + woff[kk >> 2]] = z[P16(kk)].y; }
+        for (int c = 0; c < 4; ++c)                                          // rows 4c, 4c+2 | 4c+1, 4c+3: each pair one ds_write2_b32
+        {
+            trf_e[(4 * c) * 16 + woff[c]] = z[P16(4 * c)].y; trf_e[(4 * c + 2) * 16 + woff[c]] = z[P16(4 * c + 2)].y;
+            trf_o[(4 * c + 1) * 16 + woff[c]] = z[P16(4 * c + 1)].y; trf_o[(4 * c + 3) * 16 + woff[c]] = z[P16(4 * c + 3)].y;
+        }
         wave_sync();
 #pragma unroll
         for (int q = 0; q < 4; ++q)
