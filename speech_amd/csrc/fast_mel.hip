@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
             const float v = acc[r];
             if (KIND == SPEECH_FBANK)
             {
-                if (live) { s_out[fr * p.D + eo + m] = p.lg ? floor_log(v) : v; }           // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column)
+                if (live) { s_out[fr * p.D + eo + m] = v; }                                 // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column); the log is taken on the way out
             }
             else if (KIND == SPEECH_MFCC)
             {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
             }
         }
     }
-    if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * p.D] = pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299
+    if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * p.D] = p.lg ? s_e[tid] : pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299 (its log, too, on the way out when lg)
     if (KIND == SPEECH_MFCC && tid < 4 * TILEK) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
     __syncthreads();
     if (p.ablate & 64) { if (s_mel[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
@@ -413,7 +413,16 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     // the tile's nframes x D outputs are one contiguous run of Y
     float *y = p.Y + utt.y_off + (unsigned long long)tile.frame0 * (unsigned long long)p.D;
     const int nout = (int)tile.nframes * p.D;
-    for (int i = tid; i < nout; i += NTM) { y[i] = s_out[i]; }
+    if (KIND == SPEECH_FBANK && p.lg)
+    {
+        // log-mel: the log is taken here, on the dense output tile (every lane a live value), not in the contraction's
+        // epilogue, where 16-column tiles of 10 mels leave a third of the lanes computing logs of padding
+        for (int i = tid; i < nout; i += NTM) { y[i] = floor_log(s_out[i]); }
+    }
+    else
+    {
+        for (int i = tid; i < nout; i += NTM) { y[i] = s_out[i]; }
+    }
 }
 
 template <int NZ, bool DITHER, bool PAIR, bool WIDE = false>
