@@ -229,3 +229,84 @@ def run_synthetic(spec, kind, opts, device=0, wave_audio_s=1.0e6, out_dir=None, 
     tot.update(waves=len(waves), waves_run=ran, waves_skipped=skipped, wall_s=time.perf_counter() - t0, audio_s=tot["samples"] / float(spec.sr),
                manifest=mpath, records=[man.done[w] for w in sorted(man.done)])
     return tot
+
+
+def read_wav16(path):
+    """One channel of a 16-bit PCM .wav as int16, and its sample rate."""
+    import wave
+    with wave.open(path, "rb") as w:
+        if w.getsampwidth() != 2:
+            raise ValueError("%s: only 16-bit PCM" % path)
+        x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+        return x[::w.getnchannels()].copy(), w.getframerate()
+
+
+def run_files(keys, paths, kind, opts, out_dir, rank=0, world=1, wave_bytes=1 << 30, device=0, extract=None, reader=read_wav16):
+    """Extract this rank's share of a list of .wav files in waves of at most `wave_bytes` of file size, so that host memory
+    holds one wave of audio and features at a time, never the shard (examples/extract_corpus.py).  A wave: read its files,
+    one call of speech_plan_run_host (int16 over PCIe, dither keyed by the utterance's line number), write
+    `feats.<rank>.<wave>.ark` + `.scp` under a temporary name, rename, record the wave -- with its per-feature sums, so a
+    resumed run needs no second look at finished waves -- in `manifest.<rank>.jsonl`.  `extract(xs, ids, rate) -> [W x D]`
+    replaces the device call (tests).  Returns {"sum", "sumsq", "frames", "waves", "waves_run", "waves_skipped", "arks"}."""
+    from . import api, ark
+    sizes = np.array([os.path.getsize(p) for p in paths], dtype=np.int64)
+    mine = api.shard_utterances(sizes, world)[rank] if world > 1 else np.arange(sizes.size, dtype=np.int64)
+    waves = plan_waves(mine, sizes[mine], int(wave_bytes))
+    desc = {"kind": "files", "n": int(sizes.size), "bytes": int(sizes.sum()), "names": hashlib.sha256("\n".join(keys).encode()).hexdigest()}
+    sig = _signature(desc, kind, opts, rank, world, int(wave_bytes))
+    os.makedirs(out_dir, exist_ok=True)
+    man = Manifest(os.path.join(out_dir, "manifest.%d.jsonl" % rank), sig, header={"corpus": desc, "kind": kind, "rank": rank, "world": world})
+    state = {"plan": None, "rate": None}
+
+    def device_extract(xs, ids, rate):
+        if state["plan"] is None:
+            o = dict(opts)
+            o.setdefault("sr", float(rate))
+            o.setdefault("hif", 0.5 * float(rate))
+            state["plan"] = api.Plan(kind, device=device, **o)
+        return state["plan"].run_host(xs, ids=ids)
+
+    def do_wave(w, first, count):
+        ids = mine[first:first + count]
+        xs = []
+        for i in ids:
+            x, r = reader(paths[int(i)])
+            state["rate"] = state["rate"] or r
+            if r != state["rate"]:
+                raise ValueError("%s: sample rate %d differs from the corpus's %d" % (paths[int(i)], r, state["rate"]))
+            xs.append(x)
+        feats = (extract or device_extract)(xs, ids, state["rate"])
+        name = "feats.%d.%d" % (rank, w)
+        tmp_ark, tmp_scp = os.path.join(out_dir, name + ".ark.tmp"), os.path.join(out_dir, name + ".scp.tmp")
+        open(tmp_scp, "w").close()
+        ark.write_ark(tmp_ark, [(keys[int(i)], f) for i, f in zip(ids, feats)], scp=tmp_scp)
+        with open(tmp_scp) as f:                                # the script file names the archive's final path
+            lines = f.read().replace(tmp_ark, os.path.join(out_dir, name + ".ark"))
+        with open(tmp_scp, "w") as f:
+            f.write(lines)
+        os.replace(tmp_scp, os.path.join(out_dir, name + ".scp"))
+        os.replace(tmp_ark, os.path.join(out_dir, name + ".ark"))    # last: what the manifest's existence check looks at
+        D = feats[0].shape[1] if feats else 0
+        s, q = np.zeros(D), np.zeros(D)
+        for f in feats:
+            f64 = f.astype(np.float64)
+            s += f64.sum(0)
+            q += (f64 * f64).sum(0)
+        return {"ark": name + ".ark", "bytes": os.path.getsize(os.path.join(out_dir, name + ".ark")), "utterances": int(count),
+                "frames": int(sum(f.shape[0] for f in feats)), "sum": s.tolist(), "sumsq": q.tolist()}
+
+    def exists(rec):
+        p = os.path.join(out_dir, rec["ark"])
+        return os.path.exists(p) and os.path.getsize(p) == rec.get("bytes")
+
+    ran, skipped = walk(waves, man, do_wave, exists)
+    if state["plan"] is not None:
+        state["plan"].close()
+    recs = [man.done[w] for w in sorted(man.done) if w < len(waves)]
+    D = max([len(r["sum"]) for r in recs] + [0])
+    s, q = np.zeros(D), np.zeros(D)
+    for r in recs:
+        if len(r["sum"]) == D:
+            s += np.array(r["sum"]); q += np.array(r["sumsq"])
+    return {"sum": s, "sumsq": q, "frames": int(sum(r["frames"] for r in recs)), "utterances": int(sum(r["utterances"] for r in recs)),
+            "waves": len(waves), "waves_run": ran, "waves_skipped": skipped, "arks": [os.path.join(out_dir, r["ark"]) for r in recs]}

@@ -155,3 +155,50 @@ def test_corpus_waves_resume_and_match_the_oracle(tmp_path):
                 assert key not in both
                 both[key] = m
     assert sorted(both) == sorted(feats) and all(np.array_equal(both[k], feats[k]) for k in feats)
+
+
+def test_file_corpus_streams_in_waves_and_resumes(tmp_path):
+    """corpus.run_files with a stand-in extractor: waves bounded by file size, one archive + script file per wave, per-feature
+    sums carried in the manifest, a killed run resumes after its last recorded wave and a changed option set is refused"""
+    import wave as wavmod
+    from speech_amd import ark, corpus
+    rng = np.random.default_rng(5)
+    keys, paths, lens = [], [], [3000, 500, 2500, 800, 4000, 100, 1500]
+    for i, n in enumerate(lens):
+        p = tmp_path / ("u%d.wav" % i)
+        with wavmod.open(str(p), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000)
+            w.writeframes(rng.integers(-3000, 3000, n).astype(np.int16).tobytes())
+        keys.append("utt%d" % i); paths.append(str(p))
+    calls = []
+
+    def extract(xs, ids, rate):
+        calls.append([int(i) for i in ids])
+        assert rate == 8000
+        return [np.stack([x[:len(x) // 100 * 100].reshape(-1, 100).mean(1), np.full(len(x) // 100, float(i))], 1).astype(np.float32) for x, i in zip(xs, ids)]
+
+    out = tmp_path / "out"
+    res = corpus.run_files(keys, paths, "mfcc", {"B": 23}, str(out), wave_bytes=9000, extract=extract)
+    assert res["waves"] == len(calls) >= 3 and res["waves_run"] == res["waves"] and res["utterances"] == 7
+    assert all(sum(os.path.getsize(paths[i]) for i in c) <= 9000 or len(c) == 1 for c in calls)     # a wave holds at most wave_bytes of files
+    got = {}
+    for w in range(res["waves"]):
+        got.update({k: m for k, m in ark.read_scp(str(out / ("feats.0.%d.scp" % w)))})                # script files point at the final archive names
+    assert set(got) == set(keys) and res["frames"] == sum(m.shape[0] for m in got.values())
+    allf = np.concatenate([got[k] for k in keys]).astype(np.float64)
+    assert np.allclose(res["sum"], allf.sum(0)) and np.allclose(res["sumsq"], (allf * allf).sum(0))
+    # resume: nothing to do; after losing the last wave's archive and a torn manifest line, only that wave is redone
+    n0 = len(calls)
+    res2 = corpus.run_files(keys, paths, "mfcc", {"B": 23}, str(out), wave_bytes=9000, extract=extract)
+    assert len(calls) == n0 and res2["waves_skipped"] == res["waves"] and np.allclose(res2["sum"], res["sum"])
+    os.remove(out / ("feats.0.%d.ark" % (res["waves"] - 1)))
+    with open(out / "manifest.0.jsonl", "a") as f:
+        f.write('{"wave": 99, "fir')
+    res3 = corpus.run_files(keys, paths, "mfcc", {"B": 23}, str(out), wave_bytes=9000, extract=extract)
+    assert len(calls) == n0 + 1 and res3["waves_run"] == 1 and np.allclose(res3["sum"], res["sum"])
+    with pytest.raises(ValueError):
+        corpus.run_files(keys, paths, "mfcc", {"B": 40}, str(out), wave_bytes=9000, extract=extract)
+    # two ranks: disjoint shares, together the corpus
+    r0 = corpus.run_files(keys, paths, "mfcc", {"B": 23}, str(tmp_path / "two"), rank=0, world=2, wave_bytes=9000, extract=extract)
+    r1 = corpus.run_files(keys, paths, "mfcc", {"B": 23}, str(tmp_path / "two"), rank=1, world=2, wave_bytes=9000, extract=extract)
+    assert r0["utterances"] + r1["utterances"] == 7 and np.allclose(r0["sum"] + r1["sum"], res["sum"])

@@ -93,7 +93,8 @@ def test_corpus_extraction_two_ranks_on_the_gpu(tmp_path):
     lst = tmp_path / "wav.scp"
     lst.write_text("\n".join(lines) + "\n")
     script = os.path.join(root, "examples", "extract_corpus.py")
-    common = [str(lst), "--kind", "mfcc", "--cmvn", "--opt", "dither=1.0", "--opt", "snip_edges=0"]
+    # --wave-mb 0: every utterance a wave of its own -- the streaming path with as many waves as it can have
+    common = [str(lst), "--kind", "mfcc", "--cmvn", "--apply-cmvn", "--wave-mb", "0", "--opt", "dither=1.0", "--opt", "snip_edges=0"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -102,12 +103,19 @@ def test_corpus_extraction_two_ranks_on_the_gpu(tmp_path):
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                          "--master-port", "29541", script, common[0], str(tmp_path / "two")] + common[1:], capture_output=True, env=env, timeout=300)
     assert r2.returncode == 0, r2.stderr.decode()[-2000:]
-    one = {k: m for k, _, m in ark.read_ark(str(tmp_path / "one" / "feats.0.ark"))}
+    import glob
+    one = {}
+    for path in sorted(glob.glob(str(tmp_path / "one" / "feats.0.*.ark"))):
+        one.update({k: m for k, _, m in ark.read_ark(path)})
+    assert len(glob.glob(str(tmp_path / "one" / "feats.0.*.ark"))) == 7       # seven waves of one utterance
     two = {}
     for rank in (0, 1):
-        part = {k: m for k, m in ark.read_scp(str(tmp_path / "two" / ("feats.%d.scp" % rank)))}
+        part = {}
+        for scp in sorted(glob.glob(str(tmp_path / "two" / ("feats.%d.*.scp" % rank)))):
+            part.update({k: m for k, m in ark.read_scp(scp)})
         assert part and not (set(part) & set(two))
         two.update(part)
+    assert os.path.exists(tmp_path / "two" / "cmvn.npz") and os.path.exists(tmp_path / "two" / "manifest.1.jsonl")
     assert set(one) == set(two) == {"utt%d" % i for i in range(7)}
     for k in one:
         # the sums are added in another order over two ranks: scale / offset agree to rounding, not to the bit
