@@ -324,7 +324,18 @@ def main():
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1" or launch_test
     if world > 1:
         if rehearsal:
-            dist.init_process_group("gloo")
+            # gloo's C++ side reports its connections on stdout ("[Gloo] Rank 0 is connected to ..."); stdout carries the ONE
+            # JSON line and nothing else, so file descriptor 1 points at stderr while the group forms
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

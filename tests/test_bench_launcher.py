@@ -18,6 +18,7 @@ def test_gpus_2_spawns_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, env=_env(BENCH_LAUNCH_TEST="1"), timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert [ln for ln in r.stdout.decode().split("\n") if ln.strip() and not ln.startswith("{")] == []     # stdout carries the JSON line and nothing else (gloo's chatter goes to stderr)
     lines = [ln for ln in r.stdout.decode().split("\n") if ln.startswith("{")]
     assert len(lines) == 1                                      # rank 0 alone prints
     j = json.loads(lines[0])
