@@ -57,7 +57,7 @@ constexpr int MW = 8;                   // waves per workgroup, mel kinds: with 
                                         // per mel tile, i.e. a job for every wave, and half as many workgroup barriers per frame
 constexpr int NTM = 64 * MW;            // threads per workgroup, mel kinds
 
-constexpr int PLP_TAIL_FRAMES = 64;     // plp: frames per workgroup (sub-tiles of MW x frames-per-wave); the serial tail runs once, one lane per frame
+constexpr int PLP_TAIL_FRAMES = 128;    // plp: frames per workgroup (sub-tiles of MW x frames-per-wave); the serial tail runs once, one lane per frame (two waves)
 constexpr int TILE_SPEC = 64;  // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
 constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
 constexpr int TR_WAVE_C = 2048;         // floats of a wave's slice when the transposition image is complex (spectrogram kernel)

@@ -114,8 +114,9 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     constexpr int RTK = TILEK / 16;                                         // 16-frame row tiles
     constexpr int PPK = WIDE ? PPW : (PAIR ? PP2 : PP);                     // pitch of the power tile
     // plp: the workgroup walks NSUB sub-tiles of TILEK frames through the FFT, mel and IDFT phases and only then runs the
-    // serial tail (Levinson-Durbin, one lane per frame) once, on 64 frames: one full wave instead of a half or quarter one
-    // per 32 or 16 frames, and one barrier pair less per sub-tile
+    // serial tail (Levinson-Durbin, one lane per frame) once, on 128 frames: two full waves instead of a half or quarter one
+    // per 32 or 16 frames, one barrier pair less per sub-tile, and the tail's latency (the other six waves wait for it) paid
+    // once per 128 frames (64 -> 128: -2 %; both frames of a lane pair in packed-f32 registers on one wave: no better)
     constexpr int NSUB = (KIND == SPEECH_PLP) ? PLP_TAIL_FRAMES / TILEK : 1;
     constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;                   // floats of tables in front of the slices
     extern __shared__ __attribute__((aligned(16))) float smem[];
