@@ -35,7 +35,7 @@ namespace speech {
 
 constexpr int MAX_MTILES = 8;            // mel tiles of up to 16 columns (B <= 128), balanced over the waves; cepstral tiles of 16 (C <= 96)
 
-struct FastGeom { bool ok, pair, wide; int fw, nz, tile; size_t span, ws, lds, m2; };  // m2: floats of mat2 staged in LDS (0: read from global)      // launch geometry of a plan, fast_geom()
+struct FastGeom { bool ok, pair, wide, xwide; int fw, nz, tile; size_t span, ws, lds, m2; };  // m2: floats of mat2 staged in LDS (0: read from global)      // launch geometry of a plan, fast_geom()
 
 struct FastTables {
     float *d_tab;      // win[512] (zero beyond L) | tw1[16][16] complex | tw2[8][16] complex
@@ -70,6 +70,10 @@ constexpr int PP = 258;                 // pitch of the TILE x 257 power tile (=
 // 1024-point plans ("wide": one frame on 32 lanes, frame_power_wide): win[1024] | tw1 | tw2 | tw3[8][16] complex = W1024^(k2 + 16 k1)
 constexpr int TABW_WIN = 0, TABW_TW1 = 1024, TABW_TW2 = 1536, TABW_TW3 = 1792, TABW_FLOATS = 2048;
 constexpr int PPW = 514;                // pitch of the 16 x 513 power tile of the wide mode (= 2 mod 32)
+// 2048-point plans ("xwide": one frame on the wave's 64 lanes, frame_power_xwide): win[2048] | tw1 | tw2 | tw3[9][16] complex =
+// W1024^(k2 + 16 k1) | tw4[9][16] complex = W2048^(k2 + 16 k1)   (row k1 = 8 serves bin 128 of lane k2 = 0)
+constexpr int TABX_WIN = 0, TABX_TW1 = 2048, TABX_TW2 = 2560, TABX_TW3 = 2816, TABX_TW4 = 3104, TABX_FLOATS = 3392;
+constexpr int PPX = 1026;               // pitch of the 8 x 1025 power tile of the xwide mode (= 2 mod 32)
 constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
 struct FastParams {
@@ -98,8 +102,9 @@ struct FastParams {
 
 typedef void (*kernel_fn)(const FastParams);
 // the instantiation that serves a plan: nz = rows of samples that hold data (9..16), pair = two frames per transform
-kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide);   // fast_spectrogram.hip
-kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide);   // fast_mel.hip
+kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide, bool xwide);   // fast_spectrogram.hip
+kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide, bool xwide);   // fast_mel.hip
+kernel_fn fast_mel_xwide_kernel_for(int nz, int kind, bool dither);                        // fast_mel_xwide.hip
 
 namespace {
 
@@ -695,6 +700,189 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
         const f2 t = cmul(v, g);
         const f2 xa = u + t, xb = u - t;
         const f2 qa = xa * xa, qb = xb * xb;
+        pa[k1] = qa.x + qa.y;
+        pb[k1] = qb.x + qb.y;
+    }
+}
+
+// 2048-point plans: ONE real frame of 1025 .. 2048 samples on the wave's 64 lanes.  The four decimated sequences
+// s_g[m] = x[4 m + g] (g = 0..3, 512 real points each) go to the four 16-lane groups, each exactly as frame_power treats a
+// 512-point frame (packing, 256-point complex FFT, untangle keeping the complex bins: a = 2 S_g[k], b = 2 conj S_g[256-k]),
+// and two radix-2 joins follow, each ONE exchange of one complex number per lane and k:
+//   step 1, lanes l and l ^ 32 (as frame_power_wide):  E1 = FFT1024 of the even samples = S_0 + W1024^k S_2,  O1 = that of
+//     the odd samples = S_1 + W1024^k S_3;  groups 0, 1 end with  xa = 2 F[k],  xb = 2 conj F[512-k];  groups 2, 3 with
+//     xa = 2 conj F[256-k],  xb = 2 F[256+k]   (F = E1 in groups 0, 2; O1 in groups 1, 3);
+//   step 2, lanes l and l ^ 16:  X[j] = E1[j] + W2048^j O1[j],  X[1024-j] = conj(E1[j] - W2048^j O1[j])  with j = k (group 0),
+//     512-k (group 1: conjugated operands, conj W2048^(512-k) = i W2048^k), 256-k (group 2: exp(i pi/4) W2048^k) and 256+k
+//     (group 3: exp(-i pi/4) W2048^k).
+// NZ = ceil(L / 128) rows of 128 samples hold data; fa = the frame's first sample in the slice.  With k = k2 + 16 k1 (k1 < 8;
+// k1 = 8: k = 128, meaningful in lanes k2 = 0 of groups 0 and 1 only) the lanes return 4 |X|^2 of the bins
+//   group 0: pa = k,       pb = 1024-k        group 1: pa = 512-k,   pb = 512+k
+//   group 2: pa = 256-k,   pb = 768+k         group 3: pa = 256+k,   pb = 768-k
+// (k = 0: groups 1 and 3 repeat bins 512 and 256 / 768; k = 128: groups 2 and 3 repeat groups 0 and 1.)
+template <int NZ, bool HALF, bool DITHER>
+__device__ __forceinline__ void frame_power_xwide(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
+                                                  const unsigned long long dkey, float (&pa)[9], float (&pb)[9], float &rawe)
+{
+    const int n1 = lane & 15, g = lane >> 4;
+    const int L = p.L;
+    const int i00 = 8 * n1 + g;                                             // the lane's samples of row n2: i00 + 128 n2 and that + 4
+    const int ilast = i00 + 128 * (NZ - 1);
+    const bool v0 = ilast < L, v1 = ilast + 4 < L;
+    const float *win = s_tab + TABX_WIN;
+    f2 z[16];
+    float sum = 0.0f;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2)
+    {
+        if (n2 < NZ)
+        {
+            f2 v = {fa[i00 + 128 * n2], fa[i00 + 128 * n2 + 4]};
+            if (n2 == NZ - 1) { v.x = v0 ? v.x : 0.0f; v.y = v1 ? v.y : 0.0f; }
+            z[n2] = v;
+            sum += v.x + v.y;
+        }
+        else { z[n2] = f2{0.0f, 0.0f}; }
+    }
+    if (DITHER)                                                             // c/kaldi_mfcc.c:243-262
+    {
+        // samples i00 + 128 n2 and that + 4 are the members of parity g & 1 of the Box-Muller pairs 4 n1 + (g >> 1) + 64 n2 and
+        // that + 2 (the lane of the neighbouring group draws the same pairs and takes the other member)
+        sum = 0.0f;
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            const unsigned pr = (unsigned)(4 * n1 + (g >> 1) + 64 * n2);
+            z[n2].x += dither_one(dither_bits(dkey, pr), p.dither, g & 1);
+            z[n2].y += dither_one(dither_bits(dkey, pr + 2u), p.dither, g & 1);
+            if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
+            sum += z[n2].x + z[n2].y;
+        }
+    }
+    float mean = 0.0f;
+    if (p.dc0)                                                              // c/kaldi_mfcc.c:265-271
+    {
+        float tot = row16_sum(sum);
+        tot += __shfl_xor(tot, 16, 64);
+        tot += __shfl_xor(tot, 32, 64);
+        mean = tot / (float)L;
+    }
+    const float npre = -p.preemph;
+    float e = 0.0f;
+#pragma unroll
+    for (int n2 = 0; n2 < NZ; ++n2)
+    {
+        z[n2] -= f2{mean, mean};
+        if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
+    }
+    if (p.want_pre)                                                         // c/kaldi_mfcc.c:274-279
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+    }
+    if (DITHER)
+    {
+        // the dithered samples exist in registers only.  The sample before the lane's first one is the first one of group
+        // g - 1's lane n1 (g > 0) or the second one of group 3's lane n1 - 1 (g = 0; lane 0: that of lane 15 one row up); the
+        // sample before its second one is the second one of group g - 1's lane n1 (g > 0) or the first one of group 3's lane n1
+        const int xa = ((g > 0) ? lane - 16 : (48 | ((n1 - 1) & 15))) << 2, xb = ((g > 0) ? lane - 16 : (48 | n1)) << 2;
+        float up = z[0].x;                                                  // l = 0: y[0] = d[0] - p d[0]
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            // what a lane SENDS: groups 0..2 are asked for .x through xa and .y through xb, group 3 the reverse
+            const float fa_ = __int_as_float(__builtin_amdgcn_ds_bpermute(xa, __float_as_int((g == 3) ? z[n2].y : z[n2].x)));
+            const float fb_ = __int_as_float(__builtin_amdgcn_ds_bpermute(xb, __float_as_int((g == 3) ? z[n2].x : z[n2].y)));
+            const float xp0 = (g == 0 && n1 == 0) ? up : fa_;
+            up = fa_;
+            const int i0 = i00 + 128 * n2;
+            f2 y;
+            y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
+            y.y = fmaf(npre, fb_, z[n2].y) * win[i0 + 4];
+            if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
+            z[n2] = y;
+        }
+    }
+    else
+#pragma unroll
+    for (int n2 = 0; n2 < NZ; ++n2)
+    {
+        // pre-emphasis y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0] (c/kaldi_mfcc.c:282-288), window (:291)
+        const int i0 = i00 + 128 * n2;
+        const float xp0 = fa[(i0 > 0) ? i0 - 1 : 0] - mean, xp1 = fa[i0 + 3] - mean;
+        f2 y;
+        y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
+        y.y = fmaf(npre, xp1, z[n2].y) * win[i0 + 4];
+        if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
+        z[n2] = y;
+    }
+    if (p.want_post)                                                        // c/kaldi_mfcc.c:295-301
+    {
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+    }
+    {
+        float tot = row16_sum(e);
+        tot += __shfl_xor(tot, 16, 64);
+        tot += __shfl_xor(tot, 32, 64);
+        rawe = fmaxf(tot, FLT_EPSILON);
+    }
+
+    fft256<HALF, TABX_TW1>(z, s_tab, s_tr, lane);
+    const int k2 = n1;
+
+    // untangle within the 16-lane group (as frame_power), then the two joins
+    const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
+    const int x1addr = (lane ^ 32) << 2, x2addr = (lane ^ 16) << 2;
+    const bool lane0 = (k2 == 0);
+    const bool h1 = (g & 2) != 0, h2 = (g & 1) != 0;
+    const f2 *tw2 = reinterpret_cast<const f2 *>(s_tab + TABX_TW2);
+    const f2 *tw3 = reinterpret_cast<const f2 *>(s_tab + TABX_TW3);
+    const f2 *tw4 = reinterpret_cast<const f2 *>(s_tab + TABX_TW4);
+    constexpr float H = 0.70710678118654752440f;
+    const f2 ph = (g == 0) ? f2{1.0f, 0.0f} : ((g == 1) ? f2{0.0f, 1.0f} : ((g == 2) ? f2{H, H} : f2{H, -H}));
+#pragma unroll
+    for (int k1 = 0; k1 < 9; ++k1)
+    {
+        f2 a, b;
+        if (k1 < 8)
+        {
+            const f2 zo = z[P16((15 - k1) & 15)], zs = z[P16((16 - k1) & 15)];
+            f2 zp;
+            zp.x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.x)));
+            zp.y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(zo.y)));
+            zp.x = lane0 ? zs.x : zp.x;
+            zp.y = lane0 ? zs.y : zp.y;
+            const f2 zk = z[P16(k1)];
+            const f2 ee = add_conj(zk, zp);
+            const f2 tt = cmul(mi_sub_conj(zk, zp), tw2[k1 * 16 + k2]);
+            a = ee + tt; b = ee - tt;                                       // 2 S[k], 2 conj S[256-k]
+        }
+        else
+        {
+            // bin 128 of the quarters (lane 0): S[128] = conj Z[128], so a = 2 conj Z[128] and b = 2 conj S[128] = 2 Z[128]
+            const f2 z8 = z[P16(8)];
+            a = f2{2.0f * z8.x, -2.0f * z8.y}; b = f2{2.0f * z8.x, 2.0f * z8.y};
+        }
+        // step 1 (lanes l ^ 32)
+        const f2 send1 = h1 ? a : b;
+        f2 r1;
+        r1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(x1addr, __float_as_int(send1.x)));
+        r1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(x1addr, __float_as_int(send1.y)));
+        const f2 w3 = tw3[k1 * 16 + k2];
+        const f2 u1 = h1 ? r1 : a, v1c = h1 ? b : r1;
+        const f2 g1 = h1 ? f2{-w3.y, w3.x} : w3;                            // groups 2, 3: conj W1024^(256-k) = i W1024^k
+        const f2 t1 = cmul(v1c, g1);
+        const f2 xa = u1 + t1, xb = u1 - t1;
+        // step 2 (lanes l ^ 16)
+        const f2 send2 = h2 ? xa : xb;
+        f2 r2;
+        r2.x = __int_as_float(__builtin_amdgcn_ds_bpermute(x2addr, __float_as_int(send2.x)));
+        r2.y = __int_as_float(__builtin_amdgcn_ds_bpermute(x2addr, __float_as_int(send2.y)));
+        const f2 u2 = h2 ? r2 : xa, v2c = h2 ? xb : r2;
+        const f2 t2 = cmul(v2c, cmul(tw4[k1 * 16 + k2], ph));
+        const f2 ya = u2 + t2, yb = u2 - t2;
+        const f2 qa = ya * ya, qb = yb * yb;
         pa[k1] = qa.x + qa.y;
         pb[k1] = qb.x + qb.y;
     }

@@ -21,22 +21,26 @@ constexpr size_t LDS_3_PER_CU = 42u * 1280u;
 static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
 {
     FastGeom g; memset(&g, 0, sizeof(g));
-    if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u && nfft != 2u * (size_t)NFFT)) { return g; }
+    if (o.dtype != SPEECH_F32 || (nfft != (size_t)NFFT && nfft != (size_t)NFFT / 2u && nfft != 2u * (size_t)NFFT && nfft != 4u * (size_t)NFFT)) { return g; }
     const size_t stp = (size_t)((float)o.sr * (float)o.frame_shift / 1000.0f);
-    if (stp < 2u || stp > 1024u || (stp & 1u) || L > nfft || L <= nfft / 2u) { return g; }
+    if (stp < 2u || stp > 2048u || L > nfft || L <= nfft / 2u) { return g; }
     g.pair = (nfft == (size_t)NFFT / 2u);
     g.wide = (nfft == 2u * (size_t)NFFT);
-    g.fw = g.wide ? 2 : (g.pair ? 2 * QF : QF);
-    g.nz = g.wide ? (int)((L + 63u) / 64u) : (g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u));
-    const size_t F = nfft / 2u + 1u, rows = (g.wide ? 64u : (g.pair ? 16u : 32u)) * (size_t)g.nz;
-    const size_t tabf = g.wide ? (size_t)TABW_FLOATS : (size_t)TAB_FLOATS;
+    g.xwide = (nfft == 4u * (size_t)NFFT);
+    if ((stp > 1024u || (stp & 1u)) && !g.xwide) { return g; }            // a 2048-point frame starts its wave's slice: any shift; the others read sample pairs
+    g.fw = g.xwide ? 1 : (g.wide ? 2 : (g.pair ? 2 * QF : QF));
+    g.nz = g.xwide ? (int)((L + 127u) / 128u) : (g.wide ? (int)((L + 63u) / 64u) : (g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u)));
+    const size_t F = nfft / 2u + 1u, rows = (g.xwide ? 128u : (g.wide ? 64u : (g.pair ? 16u : 32u))) * (size_t)g.nz;
+    const size_t tabf = g.xwide ? (size_t)TABX_FLOATS : (g.wide ? (size_t)TABW_FLOATS : (size_t)TAB_FLOATS);
+    // two workgroups per CU are what the 2048-point kernels are built for (128 VGPRs); the others stay below 64 KB
+    const size_t lds_max = g.xwide ? (size_t)100 * 1024u : (size_t)64 * 1024u;   // above 80 KB (long frames with many mel bins): one workgroup per CU
     g.span = (((size_t)g.fw - 1u) * stp + rows + 63u) & ~(size_t)63;        // whole 64-lane load instructions fit the slice
     if (o.kind == SPEECH_SPECTROGRAM)
     {
         g.ws = (std::max(g.span + (size_t)g.fw * F, (size_t)TR_WAVE_C) + 3u) & ~(size_t)3;      // + the wave's output, staged behind the parked audio; slices stay 16-byte aligned
         g.tile = (NT / 64) * g.fw * 4;                                      // four sub-tiles
         g.lds = (tabf + (NT / 64) * g.ws) * sizeof(float);
-        g.ok = g.lds <= 64u * 1024u;
+        g.ok = g.lds <= lds_max;
         return g;
     }
     if (o.B < 2u || o.B > 16u * MAX_MTILES) { return g; }                   // 128 mel bins
@@ -51,18 +55,20 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     const size_t T = (size_t)MW * (size_t)g.fw;                             // frames per sub-tile: one pass of the workgroup
     const size_t nsub = (o.kind == SPEECH_PLP) ? (size_t)PLP_TAIL_FRAMES / T : 1u;      // plp: sub-tiles per workgroup (fast_mel.hip)
     g.tile = (int)(T * nsub);
-    g.ws = std::max(g.span, g.wide ? (T * PPW + MW - 1) / MW : (g.pair ? (T * PP2 + MW - 1) / MW : (size_t)TR_WAVE));     // the slices together hold the power tile
+    g.ws = std::max(g.span, g.xwide ? (T * PPX + MW - 1) / MW : (g.wide ? (T * PPW + MW - 1) / MW : (g.pair ? (T * PP2 + MW - 1) / MW : (size_t)TR_WAVE)));     // the slices together hold the power tile
     // behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile | plp: autocorrelations; the mfcc / plp
     // output tile reuses the power tile's place
     const size_t extra = T * nsub + (o.kind == SPEECH_FBANK ? ((T * D + 3u) & ~(size_t)3) : T * (size_t)mel_pitch((int)cols))
                          + (o.kind == SPEECH_PLP ? T * nsub * 17u : 0u);
     if (T * nsub * D > (size_t)MW * g.ws) { return g; }
+    g.ws = (g.ws + 3u) & ~(size_t)3;                                         // slices stay 16-byte aligned
     g.lds = (tabf + MW * g.ws + extra) * sizeof(float);
-    g.ok = g.lds <= 64u * 1024u;
+    g.ok = g.lds <= lds_max;
     // the second contraction's matrix (mfcc: lifter x DCT, K2 x Cp; plp: IDFT bases, K2 x 16) rides in LDS behind the
     // tables when that does not cost a resident workgroup; otherwise the kernel reads it from global memory (L2)
     const size_t m2 = (o.kind == SPEECH_MFCC) ? cols * 16u * ((o.C + 15u) / 16u) : (o.kind == SPEECH_PLP ? cols * 16u : 0u);
-    if (g.ok && m2 > 0u && g.lds + m2 * sizeof(float) <= LDS_3_PER_CU) { g.m2 = m2; g.lds += m2 * sizeof(float); }
+    const size_t m2_max = !g.xwide ? (size_t)LDS_3_PER_CU : (g.lds <= 80u * 1024u ? (size_t)80 * 1024u : lds_max);      // 2048-point plans: two per CU up to 80 KB
+    if (g.ok && m2 > 0u && g.lds + m2 * sizeof(float) <= m2_max) { g.m2 = m2; g.lds += m2 * sizeof(float); }
     return g;
 }
 
@@ -70,9 +76,9 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft) { return fast_g
 
 int fast_tile_frames(const speech_opts &o, size_t L, size_t nfft) { return fast_geom(o, L, nfft).tile; }
 
-// Opt a kernel in to 64 KB of dynamic LDS (fast_geom admits nothing larger), once per device.  Done when the plan is
+// Opt a kernel in to 64 KB of dynamic LDS (100 KB for the 2048-point kernels; fast_geom admits nothing larger), once per device.  Done when the plan is
 // created, so that speech_batch_run itself only launches (and can be captured in a HIP graph).
-static hipError_t opt_in_lds(kernel_fn k)
+static hipError_t opt_in_lds(kernel_fn k, int bytes)
 {
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> opted;
@@ -83,7 +89,7 @@ static hipError_t opt_in_lds(kernel_fn k)
     const auto key = std::make_pair(dev, reinterpret_cast<const void *>(k));
     if (opted.insert(key).second)
     {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { opted.erase(key); }
     }
     return e;
@@ -91,8 +97,8 @@ static hipError_t opt_in_lds(kernel_fn k)
 
 static kernel_fn plan_kernel(const FastTables *t, bool dither, bool pcm)
 {
-    if (t->kind == SPEECH_SPECTROGRAM) { return fast_spectrogram_kernel_for(t->nz, dither, pcm, t->geom.pair, t->geom.wide); }
-    return fast_mel_kernel_for(t->nz, t->kind, dither, t->geom.pair, t->geom.wide);
+    if (t->kind == SPEECH_SPECTROGRAM) { return fast_spectrogram_kernel_for(t->nz, dither, pcm, t->geom.pair, t->geom.wide, t->geom.xwide); }
+    return fast_mel_kernel_for(t->nz, t->kind, dither, t->geom.pair, t->geom.wide, t->geom.xwide);
 }
 
 static hipError_t upload_floats(const std::vector<float> &h, float **d)
@@ -113,8 +119,8 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     if (err) { err->clear(); }
     const FastGeom g = fast_geom(o, L, nfft);
     if (!g.ok) { return nullptr; }
-    std::vector<float> tab(g.wide ? TABW_FLOATS : TAB_FLOATS, 0.0f);
-    const int o_win = g.wide ? TABW_WIN : TAB_WIN, o_tw1 = g.wide ? TABW_TW1 : TAB_TW1, o_tw2 = g.wide ? TABW_TW2 : TAB_TW2;
+    std::vector<float> tab(g.xwide ? TABX_FLOATS : (g.wide ? TABW_FLOATS : TAB_FLOATS), 0.0f);
+    const int o_win = g.xwide ? TABX_WIN : (g.wide ? TABW_WIN : TAB_WIN), o_tw1 = g.xwide ? TABX_TW1 : (g.wide ? TABW_TW1 : TAB_TW1), o_tw2 = g.xwide ? TABX_TW2 : (g.wide ? TABW_TW2 : TAB_TW2);
     if (g.pair) { for (size_t l = 0; l < L; ++l) { tab[TAB_WIN + 2 * l] = win[l]; tab[TAB_WIN + 2 * l + 1] = win[l]; } }      // (w, w): one factor for frame A and B
     else { for (size_t l = 0; l < L && l < nfft; ++l) { tab[o_win + l] = win[l]; } }
     const long double pi = 3.141592653589793238462643383279502884L;
@@ -130,6 +136,13 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
             const long double a = -2.0L * pi * (long double)(k2 + 16 * k1) / 1024.0L;
             tab[TABW_TW3 + (k1 * 16 + k2) * 2] = (float)cosl(a); tab[TABW_TW3 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a); } }
     }
+    if (g.xwide)
+    {
+        for (int k1 = 0; k1 < 9; ++k1) { for (int k2 = 0; k2 < 16; ++k2) {
+            const long double a3 = -2.0L * pi * (long double)(k2 + 16 * k1) / 1024.0L, a4 = -2.0L * pi * (long double)(k2 + 16 * k1) / 2048.0L;
+            tab[TABX_TW3 + (k1 * 16 + k2) * 2] = (float)cosl(a3); tab[TABX_TW3 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a3);
+            tab[TABX_TW4 + (k1 * 16 + k2) * 2] = (float)cosl(a4); tab[TABX_TW4 + (k1 * 16 + k2) * 2 + 1] = (float)sinl(a4); } }
+    }
     FastTables *t = new (std::nothrow) FastTables();
     if (!t) { if (err) { *err = "out of host memory"; } return nullptr; }
     t->d_tab = t->d_melw = t->d_mat2 = t->d_aux = nullptr;
@@ -137,7 +150,7 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     t->B = t->C = t->P = t->MP = t->Cp = t->K2 = t->ntile_m = t->ntile_c = 0;
     t->F = (int)(nfft / 2u + 1u);
     t->D = t->F;
-    const int klim = g.wide ? PPW : (g.pair ? PP2 : PP);                      // power-tile columns a k-loop may touch
+    const int klim = g.xwide ? PPX : (g.wide ? PPW : (g.pair ? PP2 : PP));                      // power-tile columns a k-loop may touch
     std::vector<float> melw, mat2, aux;
     if (o.kind != SPEECH_SPECTROGRAM)
     {
@@ -158,8 +171,10 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
         };
         // Columns are dealt to tiles of at most 16 so that the LONGEST k-loop is as short as possible: with equal column
         // counts the high tiles (wide triangles) take 2-3x the k-steps of the low ones and their waves finish last.
-        // 4 tiles (one per wave) up to 64 columns, else 8.
-        const int T = (Bi <= 64) ? std::min(4, Bi) : 8;
+        // 4 tiles (two row tiles each: a job per wave) up to 64 columns, else 8.
+        // 2048-point plans have ONE row tile per mel tile (8 frames per workgroup) and four times the bins: a job per wave
+        // takes 8 tiles (-2 %; no gain on the 1024-point plans)
+        const int T = g.xwide ? std::min(8, Bi) : ((Bi <= 64) ? std::min(4, Bi) : 8);
         std::vector<std::vector<int>> best(T + 1, std::vector<int>(Bi + 1, 1 << 30)), from(T + 1, std::vector<int>(Bi + 1, -1));
         best[0][0] = 0;
         for (int tl = 1; tl <= T; ++tl) { for (int j = tl; j <= Bi; ++j) { for (int i = std::max(tl - 1, j - 16); i < j; ++i) {
@@ -211,8 +226,9 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     if (e == hipSuccess && g.lds > 48u * 1024u)
     {
         const bool dither = (float)o.dither > FLT_EPSILON;
-        e = opt_in_lds(plan_kernel(t, dither, false));
-        if (e == hipSuccess) { e = opt_in_lds(plan_kernel(t, dither, true)); }
+        const int cap = g.xwide ? 100 * 1024 : 64 * 1024;
+        e = opt_in_lds(plan_kernel(t, dither, false), cap);
+        if (e == hipSuccess) { e = opt_in_lds(plan_kernel(t, dither, true), cap); }
     }
     if (e != hipSuccess) { if (err) { *err = hipGetErrorString(e); } fast_tables_destroy(t); return nullptr; }
     return t;

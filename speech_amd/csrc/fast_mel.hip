@@ -105,20 +105,23 @@ __device__ __forceinline__ f32x4 mfma_tile_pre(const float *arow, const float (&
 // power tile; NZ then counts rows of 16 samples.
 // WIDE (1024-point plans): 2 frames per wave, 32 lanes each (frame_power_wide), 16 frames per tile, a 16 x 514 power
 // tile; NZ counts rows of 64 samples.
-template <int NZ, int KIND, int P, bool DITHER, bool PAIR, bool WIDE = false>
-__global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
+// XW (2048-point plans): 1 frame per wave (frame_power_xwide), 8 frames per tile, an 8 x 1026 power tile that fills half
+// of a 16-row matrix-core tile (rows 8..15 repeat rows 0..7 and are dropped); NZ counts rows of 128 samples.  The slices
+// (up to 8 KB each) leave room for two workgroups per CU, so the kernel may use 128 VGPRs.
+template <int NZ, int KIND, int P, bool DITHER, bool PAIR, bool WIDE = false, bool XW = false>
+__global__ __launch_bounds__(NTM, XW ? 4 : 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
 {
-    static_assert(!(PAIR && WIDE), "one mode at a time");
-    constexpr int FWK = WIDE ? 2 : (PAIR ? 2 * QF : QF);                    // frames per wave
+    static_assert(!(PAIR && WIDE) && !(XW && (PAIR || WIDE)), "one mode at a time");
+    constexpr int FWK = XW ? 1 : (WIDE ? 2 : (PAIR ? 2 * QF : QF));         // frames per wave
     constexpr int TILEK = MW * FWK;                                         // frames per workgroup
-    constexpr int RTK = TILEK / 16;                                         // 16-frame row tiles
-    constexpr int PPK = WIDE ? PPW : (PAIR ? PP2 : PP);                     // pitch of the power tile
+    constexpr int RTK = XW ? 1 : TILEK / 16;                                // 16-frame row tiles
+    constexpr int PPK = XW ? PPX : (WIDE ? PPW : (PAIR ? PP2 : PP));        // pitch of the power tile
     // plp: the workgroup walks NSUB sub-tiles of TILEK frames through the FFT, mel and IDFT phases and only then runs the
     // serial tail (Levinson-Durbin, one lane per frame) once, on 128 frames: two full waves instead of a half or quarter one
     // per 32 or 16 frames, one barrier pair less per sub-tile, and the tail's latency (the other six waves wait for it) paid
     // once per 128 frames (64 -> 128: -2 %; both frames of a lane pair in packed-f32 registers on one wave: no better)
     constexpr int NSUB = (KIND == SPEECH_PLP) ? PLP_TAIL_FRAMES / TILEK : 1;
-    constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;                   // floats of tables in front of the slices
+    constexpr int TABK = XW ? TABX_FLOATS : (WIDE ? TABW_FLOATS : TAB_FLOATS);     // floats of tables in front of the slices
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     int lane = tid & 63;
@@ -163,7 +166,13 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     const int f = lane >> 4, k2 = lane & 15;
     float pa[9], pb[9], rawe = 1.0f;
     f2 rawe2 = {1.0f, 1.0f};
-    if (nfr > 0 && WIDE)
+    if (nfr > 0 && XW)
+    {
+        const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)),
+                                                                  (unsigned long long)((long long)tile.frame0 + fbase + fq)) : 0ull;
+        frame_power_xwide<NZ, true, DITHER>(s_aud, s_tab_l, s_tr, lane, p, dkey, pa, pb, rawe);
+    }
+    else if (nfr > 0 && WIDE)
     {
         // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds; its row is never stored)
         const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)),
@@ -210,7 +219,31 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     if (p.ablate & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILEK x 257 tile, column 257 zero
-    if (WIDE)
+    if (XW)
+    {
+        // group 0: bins k, 1024 - k; group 1: 512 - k, 512 + k; group 2: 256 - k, 768 + k; group 3: 256 + k, 768 - k
+        // (k = k2 + 16 k1; frame_power_xwide names the repeats that are not written); column 1025 is the zero a padded k-loop may touch
+        float *pr = s_pow + fq * PPK;
+        const int gg = lane >> 4;
+        if (p.amp)
+        {
+#pragma unroll
+            for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
+        }
+        const int ia = (gg == 0) ? 0 : ((gg == 1) ? 512 : 256), ib = (gg == 0) ? 1024 : ((gg == 1) ? 512 : 768);
+        const int sa = (gg == 0 || gg == 3) ? 1 : -1, sb = (gg == 1 || gg == 2) ? 1 : -1;
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+        {
+            const int k = k2 + 16 * k1;
+            const bool rep_a = (k == 0 && gg == 3), rep_b = (k == 0 && (gg & 1));
+            if (!rep_a) { pr[ia + sa * k] = pa[k1]; }
+            if (!rep_b) { pr[ib + sb * k] = pb[k1]; }
+        }
+        if (k2 == 0 && gg < 2) { pr[ia + sa * 128] = pa[8]; pr[ib + sb * 128] = pb[8]; }
+        if (lane == 0) { pr[1025] = 0.0f; s_e[fbase + fq] = rawe; }
+    }
+    else if (WIDE)
     {
         // even-group lanes hold bins k and 512 - k, odd-group lanes 256 - k and 256 + k (k = k2 + 16 k1); column 513 is the zero
         // a padded k-loop may touch
@@ -276,7 +309,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     {
         const int t = job / RTK, rt = job - t * RTK;                          // mel tile, 16-frame row tile
         const int ks = p.mel_ksteps[t];
-        const float *arow = s_pow + (16 * rt + col) * PPK + p.mel_kbeg[t] + (lane_m >> 4);
+        const float *arow = s_pow + (16 * rt + (XW ? (col & 7) : col)) * PPK + p.mel_kbeg[t] + (lane_m >> 4);
         f32x4 acc = mfma_tile_pre<KPRE, 4>(arow, wpre, ks);
         if (ks > KPRE)                                                      // a tile of few, wide filters: the rest of its k-steps in the loop form
         {
@@ -290,12 +323,13 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
             weights_issue(wpre, rb, lane_m * 4, 256);
         }
         const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
-        const bool live = col < p.mel_cnt[t];
+        const bool live_c = col < p.mel_cnt[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
             const int fr = 16 * rt + fr0 + r;
             const float v = acc[r];
+            const bool live = live_c && (!XW || fr < TILEK);
             if (KIND == SPEECH_FBANK)
             {
                 if (live) { s_out[fr * p.D + eo + m] = v; }                                 // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column); the log is taken on the way out
@@ -329,7 +363,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
         for (int job = wv; job < njob_2; job += MW)
         {
             const int t = job / RTK, rt = job - t * RTK;
-            const float *arow = s_mel + (16 * rt + col) * p.MP + (lane_m >> 4);
+            const float *arow = s_mel + (16 * rt + (XW ? (col & 7) : col)) * p.MP + (lane_m >> 4);
             const int boff = (lane_m >> 4) * p.Cp + 16 * t + col;
             const f32x4 acc = p.m2 ? mfma_tile(arow, s_m2 + boff, 4 * p.Cp, ks2) : mfma_tile(arow, p.mat2 + boff, 4 * p.Cp, ks2);
             const int c = 16 * t + col;
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
                 const int fr = 16 * rt + fr0 + r;
                 // c0 := log energy (c/kaldi_mfcc.c:327); with C == 2 the last-cepstrum copy (:333) then takes the energy too
                 const bool en = p.use_energy && (c == 0 || (c == 1 && p.C == 2));
-                if (c < p.C) { s_out[fr * p.C + c] = en ? pos_log(s_e[fr]) : acc[r]; }
+                if (c < p.C && (!XW || fr < TILEK)) { s_out[fr * p.C + c] = en ? pos_log(s_e[fr]) : acc[r]; }
             }
         }
         __syncthreads();
@@ -349,10 +383,10 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
         // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames
         if (wv < RTK)
         {
-            const float *arow = s_mel + (16 * wv + col) * p.MP + (lane_m >> 4);
+            const float *arow = s_mel + (16 * wv + (XW ? (col & 7) : col)) * p.MP + (lane_m >> 4);
             const f32x4 acc = p.m2 ? mfma_tile(arow, s_m2 + lane_m, 64, ks2) : mfma_tile(arow, p.mat2 + lane_m, 64, ks2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s_ac[(fbase + 16 * wv + fr0 + r) * 17 + col] = acc[r]; }
+            for (int r = 0; r < 4; ++r) { if (!XW || fr0 + r < TILEK) { s_ac[(fbase + 16 * wv + fr0 + r) * 17 + col] = acc[r]; } }
         }
     }
     }   // sub-tiles
@@ -426,17 +460,40 @@ __global__ __launch_bounds__(NTM, 6) void fast_mel_kernel(const FastParams p)   
     }
 }
 
-template <int NZ, bool DITHER, bool PAIR, bool WIDE = false>
+template <int NZ, bool DITHER, bool PAIR, bool WIDE = false, bool XW = false>
 kernel_fn mel_for_kind(int kind)
 {
     switch (kind)
     {
-        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER, PAIR, WIDE>;
-        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER, PAIR, WIDE>;
-        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER, PAIR, WIDE>;
+        case SPEECH_FBANK: return fast_mel_kernel<NZ, SPEECH_FBANK, 0, DITHER, PAIR, WIDE, XW>;
+        case SPEECH_MFCC: return fast_mel_kernel<NZ, SPEECH_MFCC, 0, DITHER, PAIR, WIDE, XW>;
+        default: return fast_mel_kernel<NZ, SPEECH_PLP, 12, DITHER, PAIR, WIDE, XW>;
     }
 }
 
+#if defined(SPEECH_MEL_XWIDE_TU)
+// the 2048-point instantiations are a translation unit of their own (fast_mel_xwide.hip), built beside this one
+template <bool DITHER>
+kernel_fn mel_xwide_for_nz(int nz, int kind)
+{
+    switch (nz)
+    {
+        case 9: return mel_for_kind<9, DITHER, false, false, true>(kind);
+        case 10: return mel_for_kind<10, DITHER, false, false, true>(kind);
+        case 11: return mel_for_kind<11, DITHER, false, false, true>(kind);
+        case 12: return mel_for_kind<12, DITHER, false, false, true>(kind);
+        case 13: return mel_for_kind<13, DITHER, false, false, true>(kind);
+        case 14: return mel_for_kind<14, DITHER, false, false, true>(kind);
+        case 15: return mel_for_kind<15, DITHER, false, false, true>(kind);
+        default: return mel_for_kind<16, DITHER, false, false, true>(kind);
+    }
+}
+
+}  // namespace
+
+kernel_fn fast_mel_xwide_kernel_for(int nz, int kind, bool dither) { return dither ? mel_xwide_for_nz<true>(nz, kind) : mel_xwide_for_nz<false>(nz, kind); }
+
+#else
 template <bool DITHER>
 kernel_fn mel_wide_for_nz(int nz, int kind)
 {
@@ -473,10 +530,12 @@ kernel_fn mel_for_nz(int nz, int kind, bool dither)
 
 }  // namespace
 
-kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide)
+kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide, bool xwide)
 {
+    if (xwide) { return fast_mel_xwide_kernel_for(nz, kind, dither); }
     if (wide) { return dither ? mel_wide_for_nz<true>(nz, kind) : mel_wide_for_nz<false>(nz, kind); }
     return pair ? mel_for_nz<true>(nz, kind, dither) : mel_for_nz<false>(nz, kind, dither);
 }
+#endif
 
 }  // namespace speech

@@ -8,12 +8,14 @@ namespace {
 // tile 128; NZ then counts rows of 16 samples.
 // WIDE (1024-point plans): 2 frames per wave, 32 lanes each (frame_power_wide), a sub-tile is 8 frames, a tile 32;
 // NZ counts rows of 64 samples.
-template <int NZ, bool DITHER, bool PCM, bool PAIR, bool WIDE = false>
+// XW (2048-point plans): 1 frame per wave on all 64 lanes (frame_power_xwide), a sub-tile is 4 frames, a tile 16; NZ counts
+// rows of 128 samples.
+template <int NZ, bool DITHER, bool PCM, bool PAIR, bool WIDE = false, bool XW = false>
 __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParams p)
 {
-    static_assert(!(PAIR && WIDE), "one mode at a time");
-    constexpr int TABK = WIDE ? TABW_FLOATS : TAB_FLOATS;
-    constexpr int NPK = WIDE ? 20 : NPRE;                                   // prefetch registers: 2 frames of a 1024-point plan span up to 1280 samples at 25 / 10 ms
+    static_assert(!(PAIR && WIDE) && !(XW && (PAIR || WIDE)), "one mode at a time");
+    constexpr int TABK = XW ? TABX_FLOATS : (WIDE ? TABW_FLOATS : TAB_FLOATS);
+    constexpr int NPK = (WIDE || XW) ? 20 : NPRE;                           // prefetch registers: 2 frames of a 1024-point plan span up to 1280 samples at 25 / 10 ms (a 2048-point frame of more than 1280 samples is loaded when its turn comes)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     const float *xu = p.X + ((p.ablate & 16) ? 0 : utt.x_off);
     const short *xu16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
-    constexpr int FW = WIDE ? 2 : (PAIR ? 2 * QF : QF);                     // frames per wave
+    constexpr int FW = XW ? 1 : (WIDE ? 2 : (PAIR ? 2 * QF : QF));          // frames per wave
     constexpr int SUBF = (NT / 64) * FW;                                    // frames per sub-tile
     const int nsub = ((int)tile.nframes + SUBF - 1) / SUBF;
     const unsigned long long dkey_utt = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.uid << 32)) : 0ull;
@@ -48,7 +50,12 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         f2 rawe2 = {1.0f, 1.0f};
         if (nfr > 0)
         {
-            if (WIDE)
+            if (XW)
+            {
+                const unsigned long long dkey = DITHER ? dither_frame_key(dkey_utt, (unsigned long long)((long long)tile.frame0 + fq)) : 0ull;
+                frame_power_xwide<NZ, false, DITHER>(s_aud, s_tab + opaque_zero(), s_tr, lane, p, dkey, pa, pb, rawe);
+            }
+            else if (WIDE)
             {
                 // lanes 32 j .. 32 j + 31: frame fq + j (a missing second frame computes on whatever the slice holds and is dropped)
                 const unsigned long long dkey = DITHER ? dither_frame_key(dkey_utt, (unsigned long long)((long long)tile.frame0 + fq + (lane >> 5))) : 0ull;
@@ -82,7 +89,25 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             // requests in flight, and dword stores of 64-byte runs need eight times as many for the same bytes.
             const int D = p.D;
             float *st = s_aud + p.span + f * D;
-            if (WIDE)
+            if (XW)
+            {
+                // group 0: bins k, 1024 - k; group 1: 512 - k, 512 + k; group 2: 256 - k, 768 + k; group 3: 256 + k, 768 - k; D = 1025
+                float *sw = s_aud + p.span;
+                const int gg = lane >> 4;
+                const int ia = (gg == 0) ? 0 : ((gg == 1) ? 512 : 256), ib = (gg == 0) ? 1024 : ((gg == 1) ? 512 : 768);
+                const int sa = (gg == 0 || gg == 3) ? 1 : -1, sb = (gg == 1 || gg == 2) ? 1 : -1;
+#pragma unroll
+                for (int k1 = 0; k1 < 8; ++k1)
+                {
+                    const int k = k2 + 16 * k1;
+                    const f2 l = spec_log2((k == 0 && gg == 0) ? 4.0f * rawe : pa[k1], pb[k1]);
+                    if (!(k == 0 && gg == 3)) { sw[ia + sa * k] = l.x; }
+                    if (!(k == 0 && (gg & 1)) && !(k == 0 && gg == 0)) { sw[ib + sb * k] = l.y; }
+                    if (gg == 0 && k == 1) { sw[1024] = l.y; }                                  // last bin := the one before (c/kaldi_spectrogram.c:245-247)
+                }
+                if (k2 == 0 && gg < 2) { const f2 l = spec_log2(pa[8], pb[8]); sw[ia + sa * 128] = l.x; sw[ib + sb * 128] = l.y; }
+            }
+            else if (WIDE)
             {
                 // even-group lanes hold bins k and 512 - k, odd-group lanes 256 - k and 256 + k (k = k2 + 16 k1); D = 513
                 float *sw = s_aud + p.span + (lane >> 5) * D;
@@ -144,7 +169,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(so + 4 * c);
                     __builtin_amdgcn_raw_buffer_store_b128(v, ry, c * 16, 0, 0);
                 }
-                if (WIDE && lane < 2) { const int i = 4 * (FW * D / 4) + lane; __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, so[i]), ry, i * 4, 0, 0); }      // 2 x 513 = 256 chunks + 2
+                if ((WIDE || XW) && lane < (WIDE ? 2 : 1)) { const int i = 4 * (FW * D / 4) + lane; __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, so[i]), ry, i * 4, 0, 0); }      // 2 x 513 = 256 chunks + 2
             }
             else                                                            // the last quad of an utterance: fewer frames
             {
@@ -189,6 +214,28 @@ kernel_fn spectrogram_wide_for(bool dither, bool pcm)
     return pcm ? fast_spectrogram_kernel<NZ, false, true, false, true> : fast_spectrogram_kernel<NZ, false, false, false, true>;
 }
 
+template <int NZ>
+kernel_fn spectrogram_xwide_for(bool dither, bool pcm)
+{
+    if (dither) { return pcm ? fast_spectrogram_kernel<NZ, true, true, false, false, true> : fast_spectrogram_kernel<NZ, true, false, false, false, true>; }
+    return pcm ? fast_spectrogram_kernel<NZ, false, true, false, false, true> : fast_spectrogram_kernel<NZ, false, false, false, false, true>;
+}
+
+kernel_fn spectrogram_xwide_for_nz(int nz, bool dither, bool pcm)
+{
+    switch (nz)
+    {
+        case 9: return spectrogram_xwide_for<9>(dither, pcm);
+        case 10: return spectrogram_xwide_for<10>(dither, pcm);
+        case 11: return spectrogram_xwide_for<11>(dither, pcm);
+        case 12: return spectrogram_xwide_for<12>(dither, pcm);
+        case 13: return spectrogram_xwide_for<13>(dither, pcm);
+        case 14: return spectrogram_xwide_for<14>(dither, pcm);
+        case 15: return spectrogram_xwide_for<15>(dither, pcm);
+        default: return spectrogram_xwide_for<16>(dither, pcm);
+    }
+}
+
 kernel_fn spectrogram_wide_for_nz(int nz, bool dither, bool pcm)
 {
     switch (nz)
@@ -206,8 +253,9 @@ kernel_fn spectrogram_wide_for_nz(int nz, bool dither, bool pcm)
 
 }  // namespace
 
-kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide)
+kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide, bool xwide)
 {
+    if (xwide) { return spectrogram_xwide_for_nz(nz, dither, pcm); }
     if (wide) { return spectrogram_wide_for_nz(nz, dither, pcm); }
     return pair ? spectrogram_for_nz<true>(nz, dither, pcm) : spectrogram_for_nz<false>(nz, dither, pcm);
 }

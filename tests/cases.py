@@ -80,6 +80,20 @@ for j, (sr, snip, dc0, rawe) in enumerate(((22050.0, 1, 1, 1), (32000.0, 0, 0, 0
     _add("spectrogram", [9000, 3000, 700, 12001][j], 660 + j, sr=sr, snip=snip, dc0=dc0, raw_energy=rawe,
          win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j])
 _add("mfcc", 1024, 650, sr=16000.0, fl=64.0, fs=16.0)            # L=1024 == nfft, one frame
+# 2048-point frames on the tuned kernels (one frame per wave; 44.1 / 48 kHz at 25 ms, odd frame shifts included): every
+# switch, several 8- / 16- / 128-frame tiles, short signals with reflected edges
+for i, (kind, extra) in enumerate((("fbank", dict(B=80)), ("fbank", dict(B=40, amp=1, use_energy=1)), ("mfcc", dict(B=23, C=13)),
+                                   ("mfcc", dict(B=40, C=40, use_energy=1)), ("plp", dict(B=23, C=13)), ("plp", dict(B=23, C=13, compress=0.5)))):
+    for j, (sr, snip, dc0, rawe) in enumerate(((44100.0, 1, 1, 1), (48000.0, 0, 0, 0), (48000.0, 0, 1, 0), (44100.0, 1, 0, 1))):
+        _add(kind, [20000, 6000, 1300, 70001][j], 900 + 4 * i + j, sr=sr, hif=sr / 2, snip=snip, dc0=dc0, raw_energy=rawe,
+             win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j], **extra)
+for j, (sr, snip, dc0, rawe) in enumerate(((44100.0, 1, 1, 1), (48000.0, 0, 0, 0), (48000.0, 0, 1, 0), (44100.0, 1, 0, 1))):
+    _add("spectrogram", [20000, 6000, 1300, 30001][j], 930 + j, sr=sr, snip=snip, dc0=dc0, raw_energy=rawe,
+         win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j])
+_add("mfcc", 2048, 940, sr=16000.0, fl=128.0, fs=32.0)           # L=2048 == nfft, one frame
+_add("fbank", 9000, 941, sr=16000.0, fl=64.0625, fs=10.0, B=23)   # L=1025: the shortest 2048-point frame
+_add("spectrogram", 9000, 944, sr=16000.0, fl=100.0, fs=12.5, snip=0)   # L=1600, stp=200 (seed 942: passes the rms clause at 0.97, its largest deviation is 2.1 x the CPU arithmetic's against the 2 x allowed)
+_add("plp", 40000, 943, sr=48000.0, hif=24000.0, fs=40.0, snip=0)       # stp=1920 > L=1200: gaps between frames
 _add("fbank", 3000, 651, sr=16000.0, fl=32.0625, fs=10.0, B=23)   # L=513: the shortest 1024-point frame
 _add("mfcc", 3000, 605, sr=16000.0, fl=10.0, fs=5.0)             # L=160 -> nfft 256
 _add("spectrogram", 3000, 606, sr=16000.0, fl=32.0, fs=16.0)     # L=512 == nfft

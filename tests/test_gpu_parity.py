@@ -178,7 +178,9 @@ def test_tuned_and_generic_kernels_agree():
                     ("spectrogram", dict(sr=8000.0)), ("mfcc", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(sr=8000.0, hif=4000.0, B=40, snip=0)),
                     ("plp", dict(sr=8000.0, hif=4000.0)), ("fbank", dict(B=128, use_energy=1)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100, snip=0)),
                     ("fbank", dict(sr=22050.0, hif=11025.0, B=80)), ("mfcc", dict(sr=32000.0, hif=15000.0, snip=0)), ("plp", dict(sr=24000.0, hif=12000.0)),
-                    ("mfcc", dict(fl=64.0, fs=16.0, B=40, C=40, hif=7600.0)), ("spectrogram", dict(sr=22050.0)), ("spectrogram", dict(sr=32000.0, snip=0, dc0=0, preemph=0.0, win="hann")), ("fbank", dict(sr=22050.0, hif=11025.0, fl=46.44, fs=11.61, B=80, win="hann", preemph=0.0, dc0=0, snip=0))]:
+                    ("mfcc", dict(fl=64.0, fs=16.0, B=40, C=40, hif=7600.0)), ("spectrogram", dict(sr=22050.0)), ("spectrogram", dict(sr=32000.0, snip=0, dc0=0, preemph=0.0, win="hann")), ("fbank", dict(sr=22050.0, hif=11025.0, fl=46.44, fs=11.61, B=80, win="hann", preemph=0.0, dc0=0, snip=0)),
+                    ("fbank", dict(sr=48000.0, hif=24000.0, B=80)), ("mfcc", dict(sr=44100.0, hif=20000.0, snip=0)), ("plp", dict(sr=48000.0, hif=24000.0)),
+                    ("spectrogram", dict(sr=44100.0)), ("spectrogram", dict(sr=48000.0, snip=0, dc0=0, preemph=0.0, win="hann")), ("mfcc", dict(fl=128.0, fs=32.0, B=40, C=40, hif=7600.0))]:
         x = signals.utterance(24000, 77, sr=o.get("sr", 16000.0))
         X = torch.from_numpy(x).cuda()
         outs = []
@@ -193,8 +195,10 @@ def test_tuned_and_generic_kernels_agree():
         for fg, got in enumerate(outs):
             # the generic kernels (coverage path: any frame size, f64) are a plain radix-2 pipeline, a little noisier than the
             # tuned ones: their rms noise may reach 1.5 x the CPU arithmetic's (measured 1.25 on this input), the tuned
-            # kernels keep the suite's 1.25
-            ok, msg = _parity(kind, o, x, got, margin=1.5 if fg else None)
+            # kernels keep the suite's 1.25.  On 2048-point frames the generic spectrogram measured 1.65 (ten radix-2 stages
+            # with float twiddles; the tuned 2048-point kernels: within 1.25 like the rest): 1.75 there
+            gm = 1.75 if (kind == "spectrogram" and o.get("sr", 16000.0) >= 44100.0) else 1.5
+            ok, msg = _parity(kind, o, x, got, margin=gm if fg else None)
             assert ok, (kind, fg, msg)
         # mutual bound: 2e-4, or twice the distance of the float32 CPU oracle from a float64 statement of the same
         # algorithm where that is larger (this tonal signal puts weak bins at the float32 FFT noise floor; the 80-bin
@@ -450,7 +454,9 @@ def test_dither_is_seeded_and_has_the_right_scale():
                                     ("mfcc", dict(sr=8000.0, hif=4000.0)), ("spectrogram", dict(sr=8000.0, snip=0)),
                                     ("fbank", dict(sr=8000.0, hif=3800.0, B=40, fl=32.0, preemph=0.0)),
                                     ("mfcc", dict(sr=22050.0, hif=11025.0)), ("spectrogram", dict(sr=32000.0, snip=0)),
-                                    ("fbank", dict(sr=24000.0, hif=12000.0, B=40, preemph=0.0, dc0=0, raw_energy=0, use_energy=1)), ("plp", dict(fl=64.0, fs=16.0))])
+                                    ("fbank", dict(sr=24000.0, hif=12000.0, B=40, preemph=0.0, dc0=0, raw_energy=0, use_energy=1)), ("plp", dict(fl=64.0, fs=16.0)),
+                                    ("mfcc", dict(sr=44100.0, hif=22050.0)), ("spectrogram", dict(sr=48000.0, snip=0)), ("plp", dict(sr=48000.0, hif=24000.0, snip=0)),
+                                    ("fbank", dict(fl=128.0, fs=32.0, B=40, preemph=0.0, dc0=0, raw_energy=0, use_energy=1))])
 def test_dithered_frames_tuned_and_generic_draw_the_same_noise(kind, o):
     """dither (c/kaldi_mfcc.c:243-262) is per frame and counter-based: the tuned kernels (noise added in registers, the
     pre-emphasis neighbour fetched across lanes) and the generic kernel (noise added in LDS) see the same dithered frames,
@@ -487,9 +493,11 @@ def test_which_plans_run_on_the_tuned_kernels():
              ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("spectrogram", dict(sr=8000.0)), ("plp", dict(sr=8000.0, hif=3800.0)), ("fbank", dict(fl=10.0, fs=5.0, B=40)),
              ("fbank", dict(B=128)), ("mfcc", dict(B=128, C=80)), ("plp", dict(B=100)),
              ("fbank", dict(sr=22050.0, hif=11025.0, B=80)), ("mfcc", dict(sr=32000.0, hif=16000.0)), ("plp", dict(sr=24000.0, hif=12000.0)), ("mfcc", dict(fl=64.0, fs=20.0)), ("spectrogram", dict(sr=22050.0)), ("spectrogram", dict(sr=32000.0)),
-             ("mfcc", dict(sr=22050.0, hif=11025.0, dither=1.0)), ("spectrogram", dict(sr=22050.0, dither=1.0))]
-    generic = [("mfcc", dict(sr=4000.0, hif=2000.0, B=15)), ("spectrogram", dict(sr=44100.0)), ("mfcc", dict(sr=16100.0)),
-               ("fbank", dict(sr=44100.0, hif=22050.0)),
+             ("mfcc", dict(sr=22050.0, hif=11025.0, dither=1.0)), ("spectrogram", dict(sr=22050.0, dither=1.0)),
+             ("spectrogram", dict(sr=44100.0)), ("fbank", dict(sr=44100.0, hif=22050.0)), ("mfcc", dict(sr=48000.0, hif=24000.0, dither=1.0)), ("plp", dict(sr=48000.0, hif=24000.0)),
+             ("fbank", dict(fl=128.0, fs=40.0, B=128))]
+    generic = [("mfcc", dict(sr=4000.0, hif=2000.0, B=15)), ("spectrogram", dict(sr=96000.0)), ("mfcc", dict(sr=16100.0)),
+               ("fbank", dict(sr=96000.0, hif=22050.0)),
                ("plp", dict(order=16)), ("fbank", dict(B=129)), ("mfcc", dict(fs=10.0625)), ("fbank", dict(B=1))]
     for kind, o in tuned:
         assert api.Plan(kind, **o).tuned, (kind, o)
@@ -500,7 +508,8 @@ def test_which_plans_run_on_the_tuned_kernels():
 
 @pytest.mark.parametrize("kind,o,dtype,pcm", [("mfcc", {}, "f32", False), ("spectrogram", dict(snip=0), "f32", False), ("fbank", dict(B=40, dither=1.0), "f32", False),
                                                ("mfcc", dict(mn0=1, snip=0), "f64", False), ("plp", {}, "f32", True), ("fbank", dict(sr=8000.0, hif=4000.0, dither=0.5), "f64", True),
-                                               ("fbank", dict(sr=22050.0, hif=11025.0, B=80, snip=0), "f32", True)])
+                                               ("fbank", dict(sr=22050.0, hif=11025.0, B=80, snip=0), "f32", True),
+                                               ("mfcc", dict(sr=44100.0, hif=22050.0, snip=0), "f32", True)])
 def test_run_host_equals_the_resident_batch(kind, o, dtype, pcm):
     """speech_plan_run_host: host pointers in and out, chunked over two streams -- the features of the whole list as one
     resident batch, bit for bit (dither included: the chunks carry the utterances' numbers), for any chunk size"""

@@ -3,7 +3,9 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from speech_amd import api
-for kind, dtype, o in (("mfcc", "f32", dict(force_generic=1)), ("mfcc", "f64", {}), ("spectrogram", "f64", {}), ("fbank", "f32", dict(sr=22050.0, hif=11025.0, B=40))):
+for kind, dtype, o in (("mfcc", "f32", dict(force_generic=1)), ("mfcc", "f64", {}), ("spectrogram", "f64", {}), ("fbank", "f32", dict(sr=22050.0, hif=11025.0, B=40)),
+                       ("fbank", "f32", dict(sr=48000.0, hif=24000.0, B=80, force_generic=1)), ("mfcc", "f32", dict(sr=44100.0, hif=22050.0, force_generic=1)),
+                       ("spectrogram", "f32", dict(sr=48000.0, force_generic=1))):
     plan = api.Plan(kind, dtype=dtype, snip=1, dc0=1, raw_energy=1, **o)
     n = int(10 * o.get("sr", 16000.0))
     b = api.Batch(plan, [n] * 200)
