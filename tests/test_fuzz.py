@@ -1,5 +1,6 @@
 """Differential fuzz of the two HIP implementations: random option sets inside the tuned kernels' envelope (8 / 16 / 32 kHz,
-frame lengths 129..1024 samples, even shifts, every switch, ragged utterance lengths, both edge modes) must give the same
+frame lengths 129..1024 samples, even shifts; 48 kHz, 1025..2048 samples, any shift; every switch, ragged utterance lengths,
+both edge modes) must give the same
 features on the tuned and on the generic kernels (force_generic), and pass the parity suite's acceptance rule against the
 CPU oracle."""
 import numpy as np
@@ -13,15 +14,18 @@ from compare import check_parity, max_err
 WINDOWS = ("povey", "hamming", "hann", "rectangular", "blackman")
 
 
-def _configs(n, seed):
+def _configs(n, seed, xw=False):
+    """xw: 2048-point sets only (48 kHz, L = 1025..2048, odd and even shifts); otherwise the 256- / 512- / 1024-point mix"""
     rng = np.random.default_rng(seed)
     out = []
     for i in range(n):
-        sr = float(rng.choice([8000.0, 16000.0, 32000.0]))
+        sr = 48000.0 if xw else float(rng.choice([8000.0, 16000.0, 32000.0]))
         # frame length so that L lands in 129..256 (8 kHz), 257..512 (16 kHz) or 513..1024 (32 kHz), in whole samples
         L = int(rng.integers(129, 257)) if sr == 8000.0 else (int(rng.integers(257, 513)) if sr == 16000.0 else int(rng.integers(513, 1025)))
+        if xw:
+            L = int(rng.integers(1025, 2049))
         fl = (L + 0.5) * 1000.0 / sr
-        stp = 2 * int(rng.integers(10, 200))
+        stp = int(rng.integers(40, 900)) if xw else 2 * int(rng.integers(10, 200))
         fs = (stp + 0.25) * 1000.0 / sr
         kind = str(rng.choice(["spectrogram", "fbank", "mfcc", "plp"]))
         o = dict(sr=sr, fl=fl, fs=fs, snip=int(rng.integers(0, 2)), dc0=int(rng.integers(0, 2)), raw_energy=int(rng.integers(0, 2)),
@@ -36,18 +40,18 @@ def _configs(n, seed):
             o.update(C=int(rng.integers(2, min(o["B"], 40) + 1)), Q=float(rng.choice([0.0, 22.0])))
         if kind == "plp":
             o.update(B=int(rng.integers(15, 41)), C=13, Q=float(rng.choice([0.0, 22.0])))
-        lens = [int(rng.integers(L, 40 * L)) for _ in range(3)] + [L, L + stp]
+        lens = [int(rng.integers(L, (12 if xw else 40) * L)) for _ in range(3)] + [L, L + stp]
         out.append((kind, o, lens, L, stp))
     return out
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18, 2048, 2049, 2050])
 def test_random_option_sets_tuned_equals_generic(seed):
     import torch
     from speech_amd import api
     worst, ntuned = 0.0, 0
-    for kind, o, lens, L, stp in _configs(25, seed):
+    for kind, o, lens, L, stp in _configs(25, seed, xw=seed >= 2048):
         probe = api.Plan(kind, **o)
         tuned = probe.tuned
         probe.close()
@@ -84,7 +88,7 @@ def test_random_option_sets_tuned_equals_generic(seed):
         # from the float64 statement in the MAXIMUM norm (measured over 60 such sets: tuned 0.4-2.8 x, generic 0.6-4 x), hence the
         # wider bound on the largest deviation there; the rms noise level keeps the suite's margin (compare.MARGIN)
         ok, e_go, e_gt, e_ot = check_parity(kind, o, got0, ref, truth, tol=1e-5 if kind == "spectrogram" else 1e-4, oracle_fast=ref_fast,
-                                            max_margin=3.0 if o["sr"] == 32000.0 else 2.0)
+                                            max_margin=3.0 if o["sr"] >= 32000.0 else 2.0)
         assert ok, (kind, str(o), lens[u0], "hip-vs-oracle %.3g, hip-vs-f64 %.3g, f32-cpu-vs-f64 %.3g" % (e_go, e_gt, e_ot))
         for u, (t, g) in enumerate(zip(*outs)):
             if t.shape[0] == 0:

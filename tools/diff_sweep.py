@@ -1,5 +1,5 @@
 """Extended differential sweep of the tuned against the generic kernels (the option generator of tests/test_fuzz.py over many
-more seeds, each set with and without dither): python tools/diff_sweep.py [first_seed] [n_seeds].  Prints the worst distance
+more seeds, each set with and without dither): python tools/diff_sweep.py [first_seed] [n_seeds] [xw]   (xw: 2048-point sets only).  Prints the worst distance
 per feature kind; a defect of one implementation shows up as a distance far above 1e-3 (round 1: mfcc with use_energy and C == 2)."""
 import os, sys, numpy as np, torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -12,8 +12,9 @@ worst = {}
 n = 0
 S0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+XW = len(sys.argv) > 3 and sys.argv[3] == "xw"
 for seed in range(S0, S0 + NS):
-    for kind, o, lens, L, stp in _configs(25, seed):
+    for kind, o, lens, L, stp in _configs(25, seed, xw=XW):
         for dither in (0.0, 2.0):
             oo = dict(o, dither=dither, dither_seed=seed)
             p0 = api.Plan(kind, **oo)
