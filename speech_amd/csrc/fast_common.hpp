@@ -70,9 +70,13 @@ constexpr int PP = 258;                 // pitch of the TILE x 257 power tile (=
 // 1024-point plans ("wide": one frame on 32 lanes, frame_power_wide): win[1024] | tw1 | tw2 | tw3[8][16] complex = W1024^(k2 + 16 k1)
 constexpr int TABW_WIN = 0, TABW_TW1 = 1024, TABW_TW2 = 1536, TABW_TW3 = 1792, TABW_FLOATS = 2048;
 constexpr int PPW = 514;                // pitch of the 16 x 513 power tile of the wide mode (= 2 mod 32)
-// 2048-point plans ("xwide": one frame on the wave's 64 lanes, frame_power_xwide): win[2048] | tw1 | tw2 | tw3[9][16] complex =
-// W1024^(k2 + 16 k1) | tw4[9][16] complex = W2048^(k2 + 16 k1)   (row k1 = 8 serves bin 128 of lane k2 = 0)
-constexpr int TABX_WIN = 0, TABX_TW1 = 2048, TABX_TW2 = 2560, TABX_TW3 = 2816, TABX_TW4 = 3104, TABX_FLOATS = 3392;
+// 2048-point plans ("xwide": one frame on the wave's 64 lanes, frame_power_xwide): win[2048, padded] | tw1 | tw2 | tw3[9][16] complex =
+// W1024^(k2 + 16 k1) | tw4[9][16] complex = W2048^(k2 + 16 k1)   (row k1 = 8 serves bin 128 of lane k2 = 0).
+// A lane of that mode reads samples (and window factors) 8 apart, which in a dense array puts 32 lanes on 8 banks; the
+// audio slice and the window table therefore carry 2 floats of padding after every 32 (sample i lives at padx(i)):
+// 8 a + 2 b + g (a, b = 0..3, g = 0..1) are 32 different banks, and the rows of 64 samples the loads park stay conflict-free.
+__host__ __device__ constexpr int padx(int i) { return i + 2 * (i >> 5); }
+constexpr int TABX_WIN = 0, TABX_TW1 = 2176, TABX_TW2 = 2688, TABX_TW3 = 2944, TABX_TW4 = 3232, TABX_FLOATS = 3520;
 constexpr int PPX = 1026;               // pitch of the 8 x 1025 power tile of the xwide mode (= 2 mod 32)
 constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
@@ -272,8 +276,11 @@ __device__ __forceinline__ f2 spec_log2(float qa, float qb)
 // the utterance is 16-bit PCM at xu16 and is converted here (exact), otherwise float at xu.
 // Interior quads use raw buffer loads: one sample per lane per instruction, lane offset in one VGPR, the step in an
 // SGPR, and the descriptor's range check instead of a per-lane bound test.
+template <bool PADX = false>
 __device__ __forceinline__ void load_span(float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int lane)
 {
+    constexpr int ROW = PADX ? 68 : 64;                                     // floats between the rows of 64 samples (padx)
+    const int lofs = PADX ? lane + 2 * (lane >> 5) : lane;
     if (s0 >= 0 && s0 + need <= N)
     {
         const int nit = (need + 63) >> 6;
@@ -289,7 +296,7 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, const s
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { v[j] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, (c + j) * 128, 0); }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { if (c + j < nit) { s_aud[lane + 64 * (c + j)] = (float)(short)v[j]; } }
+                for (int j = 0; j < 16; ++j) { if (c + j < nit) { s_aud[lofs + ROW * (c + j)] = (float)(short)v[j]; } }
             }
         }
         else
@@ -301,7 +308,7 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, const s
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, (c + j) * 256, 0)); }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { if (c + j < nit) { s_aud[lane + 64 * (c + j)] = v[j]; } }
+                for (int j = 0; j < 16; ++j) { if (c + j < nit) { s_aud[lofs + ROW * (c + j)] = v[j]; } }
             }
         }
     }
@@ -311,7 +318,7 @@ __device__ __forceinline__ void load_span(float *s_aud, const float *xu, const s
         {
             long long n = s0 + i;
             while (n < 0 || n >= N) { n = (n < 0) ? -n - 1 : 2 * N - 1 - n; }
-            s_aud[i] = xu16 ? (float)xu16[n] : xu[n];
+            s_aud[PADX ? padx(i) : i] = xu16 ? (float)xu16[n] : xu[n];
         }
     }
 }
@@ -729,6 +736,9 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
     const int i00 = 8 * n1 + g;                                             // the lane's samples of row n2: i00 + 128 n2 and that + 4
     const int ilast = i00 + 128 * (NZ - 1);
     const bool v0 = ilast < L, v1 = ilast + 4 < L;
+    // padded positions (padx): a row of 128 samples is 136 floats on; i00 .. i00 + 4 share a block of 32, i00 - 1 may not
+    const int q00 = padx(i00);
+    const int qm0 = (i00 > 0) ? padx(i00 - 1) : 0, qm = (i00 > 0) ? padx(i00 - 1) : -3;      // sample before the first one: row 0 (itself for l = 0), rows n2 > 0
     const float *win = s_tab + TABX_WIN;
     f2 z[16];
     float sum = 0.0f;
@@ -737,7 +747,7 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
     {
         if (n2 < NZ)
         {
-            f2 v = {fa[i00 + 128 * n2], fa[i00 + 128 * n2 + 4]};
+            f2 v = {fa[q00 + 136 * n2], fa[q00 + 136 * n2 + 4]};
             if (n2 == NZ - 1) { v.x = v0 ? v.x : 0.0f; v.y = v1 ? v.y : 0.0f; }
             z[n2] = v;
             sum += v.x + v.y;
@@ -795,10 +805,10 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
             const float fb_ = __int_as_float(__builtin_amdgcn_ds_bpermute(xb, __float_as_int((g == 3) ? z[n2].x : z[n2].y)));
             const float xp0 = (g == 0 && n1 == 0) ? up : fa_;
             up = fa_;
-            const int i0 = i00 + 128 * n2;
+            const int q0 = q00 + 136 * n2;
             f2 y;
-            y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
-            y.y = fmaf(npre, fb_, z[n2].y) * win[i0 + 4];
+            y.x = fmaf(npre, xp0, z[n2].x) * win[q0];
+            y.y = fmaf(npre, fb_, z[n2].y) * win[q0 + 4];
             if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
             z[n2] = y;
         }
@@ -808,11 +818,11 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
     for (int n2 = 0; n2 < NZ; ++n2)
     {
         // pre-emphasis y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0] (c/kaldi_mfcc.c:282-288), window (:291)
-        const int i0 = i00 + 128 * n2;
-        const float xp0 = fa[(i0 > 0) ? i0 - 1 : 0] - mean, xp1 = fa[i0 + 3] - mean;
+        const int q0 = q00 + 136 * n2;
+        const float xp0 = fa[(n2 == 0) ? qm0 : qm + 136 * n2] - mean, xp1 = fa[q0 + 3] - mean;
         f2 y;
-        y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
-        y.y = fmaf(npre, xp1, z[n2].y) * win[i0 + 4];
+        y.x = fmaf(npre, xp0, z[n2].x) * win[q0];
+        y.y = fmaf(npre, xp1, z[n2].y) * win[q0 + 4];
         if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
         z[n2] = y;
     }
@@ -1074,15 +1084,17 @@ __device__ __forceinline__ void prefetch_issue(Prefetch<NP> &pf, const FastParam
     }
 }
 
-template <bool PCM, int NP = NPRE>
+template <bool PCM, int NP = NPRE, bool PADX = false>
 __device__ __forceinline__ void prefetch_park(const Prefetch<NP> &pf, float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane, int ablate)
 {
     if (pf.on)
     {
+        constexpr int ROW = PADX ? 68 : 64;
+        const int lofs = PADX ? lane + 2 * (lane >> 5) : lane;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) { s_aud[lane + 64 * j] = PCM ? (float)(short)(unsigned short)__builtin_bit_cast(unsigned, pf.v[j]) : pf.v[j]; }
+        for (int j = 0; j < NP; ++j) { s_aud[lofs + ROW * j] = PCM ? (float)(short)(unsigned short)__builtin_bit_cast(unsigned, pf.v[j]) : pf.v[j]; }
     }
-    else if (nfr > 0 && !(ablate & 2)) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
+    else if (nfr > 0 && !(ablate & 2)) { load_span<PADX>(s_aud, xu, xu16, s0, need, N, lane); }
 }
 
 }  // namespace

@@ -35,6 +35,7 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     // two workgroups per CU are what the 2048-point kernels are built for (128 VGPRs); the others stay below 64 KB
     const size_t lds_max = g.xwide ? (size_t)100 * 1024u : (size_t)64 * 1024u;   // above 80 KB (long frames with many mel bins): one workgroup per CU
     g.span = (((size_t)g.fw - 1u) * stp + rows + 63u) & ~(size_t)63;        // whole 64-lane load instructions fit the slice
+    if (g.xwide) { g.span += 2u * (g.span / 32u); }                        // 2 floats of padding per 32 samples (padx, fast_common.hpp)
     if (o.kind == SPEECH_SPECTROGRAM)
     {
         g.ws = (std::max(g.span + (size_t)g.fw * F, (size_t)TR_WAVE_C) + 3u) & ~(size_t)3;      // + the wave's output, staged behind the parked audio; slices stay 16-byte aligned
@@ -122,6 +123,7 @@ FastTables *fast_tables_create(const speech_opts &o, size_t L, size_t, size_t nf
     std::vector<float> tab(g.xwide ? TABX_FLOATS : (g.wide ? TABW_FLOATS : TAB_FLOATS), 0.0f);
     const int o_win = g.xwide ? TABX_WIN : (g.wide ? TABW_WIN : TAB_WIN), o_tw1 = g.xwide ? TABX_TW1 : (g.wide ? TABW_TW1 : TAB_TW1), o_tw2 = g.xwide ? TABX_TW2 : (g.wide ? TABW_TW2 : TAB_TW2);
     if (g.pair) { for (size_t l = 0; l < L; ++l) { tab[TAB_WIN + 2 * l] = win[l]; tab[TAB_WIN + 2 * l + 1] = win[l]; } }      // (w, w): one factor for frame A and B
+    else if (g.xwide) { for (size_t l = 0; l < L && l < nfft; ++l) { tab[TABX_WIN + padx((int)l)] = win[l]; } }
     else { for (size_t l = 0; l < L && l < nfft; ++l) { tab[o_win + l] = win[l]; } }
     const long double pi = 3.141592653589793238462643383279502884L;
     for (int k2 = 0; k2 < 16; ++k2) { for (int n1 = 0; n1 < 16; ++n1) {

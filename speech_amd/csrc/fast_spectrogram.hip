@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
     const unsigned long long dkey_utt = DITHER ? mix64(p.seed ^ ((unsigned long long)tile.uid << 32)) : 0ull;
     long long s0; int need;
     int nfr = quad_geom(p, tile, wv * FW, s0, need, FW);
-    if (nfr > 0) { load_span(s_aud, xu, xu16, s0, need, N, lane); }
+    if (nfr > 0) { load_span<XW>(s_aud, xu, xu16, s0, need, N, lane); }
     __syncthreads();                                                        // tables (and, wave-locally, the first span) are in LDS
 
     const int f = lane >> 4, k2 = lane & 15;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         // BEFORE this quad's stores are issued.  The loads were issued ahead of the whole FFT, and vmcnt retires in order,
         // so waiting for them here waits for nothing younger; the stores then drain behind the next quad's arithmetic.
         wave_sync();
-        prefetch_park<PCM, NPK>(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
+        prefetch_park<PCM, NPK, XW>(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
         wave_sync();
         if (nfr > 0)
         {
