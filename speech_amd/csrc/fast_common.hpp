@@ -204,6 +204,30 @@ __device__ __forceinline__ f2 pair_hi(f2 a, f2 b)
     return d;
 }
 
+// The radix-2 joins of the 1024- and 2048-point plans pair lane l with lane l ^ 16 (or l ^ 32): the lower lane of a pair
+// computes from both lanes' `a`, the upper one from both lanes' `b`.  v_permlane16_swap_b32 / v_permlane32_swap_b32 (gfx950;
+// semantics printed by tools/ubench/permlane_swap.hip) exchange exactly that in one VALU instruction per register:
+// afterwards u = (own a | the lower partner's b), v = (the upper partner's a | own b) -- no LDS crossbar trip, no wait, and
+// none of the six selects per complex pair that the ds_bpermute form needed to pick what to send and what to keep.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int ROWS32>
+__device__ __forceinline__ void join_swap(const f2 a, const f2 b, f2 &u, f2 &v)
+{
+    u32x2 rx, ry;
+    if (ROWS32)
+    {
+        rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+        ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    }
+    else
+    {
+        rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+        ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    }
+    u = f2{__uint_as_float(rx.x), __uint_as_float(ry.x)};
+    v = f2{__uint_as_float(rx.y), __uint_as_float(ry.y)};
+}
+
 // forward 4-point DFT in place: (a,b,c,d) = x0..x3 -> X0..X3
 __device__ __forceinline__ void fft4(f2 &a, f2 &b, f2 &c, f2 &d)
 {
@@ -564,8 +588,9 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
     const int ilast = i00 + 64 * (NZ - 1);
     const bool v0 = ilast < L, v1 = ilast + 2 < L;
     const float *win = s_tab + TABW_WIN;
+    // the lane's two samples of a row travel as one packed pair: sums, mean, pre-emphasis and window are v_pk_* instructions
     f2 z[16];
-    float sum = 0.0f;
+    f2 sum2 = {0.0f, 0.0f};
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2)
     {
@@ -574,7 +599,7 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
             f2 v = {fa[i00 + 64 * n2], fa[i00 + 64 * n2 + 2]};
             if (n2 == NZ - 1) { v.x = v0 ? v.x : 0.0f; v.y = v1 ? v.y : 0.0f; }
             z[n2] = v;
-            sum += v.x + v.y;
+            sum2 += v;
         }
         else { z[n2] = f2{0.0f, 0.0f}; }
     }
@@ -582,7 +607,7 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
     {
         // samples i00 + 64 n2 and that + 2 are the members of parity h of the Box-Muller pairs 2 n1 + 32 n2 and the next one
         // (the lane of the other group draws the same pairs and takes the other member)
-        sum = 0.0f;
+        sum2 = f2{0.0f, 0.0f};
 #pragma unroll
         for (int n2 = 0; n2 < NZ; ++n2)
         {
@@ -590,28 +615,29 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
             z[n2].x += dither_one(dither_bits(dkey, pr), p.dither, h);
             z[n2].y += dither_one(dither_bits(dkey, pr + 1u), p.dither, h);
             if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
-            sum += z[n2].x + z[n2].y;
+            sum2 += z[n2];
         }
     }
     float mean = 0.0f;
     if (p.dc0)                                                              // c/kaldi_mfcc.c:265-271
     {
-        float tot = row16_sum(sum);
+        float tot = row16_sum(sum2.x + sum2.y);
         tot += __shfl_xor(tot, 16, 64);
         mean = tot / (float)L;
     }
     const float npre = -p.preemph;
-    float e = 0.0f;
+    const f2 mean2 = {mean, mean}, npre2 = {npre, npre};
+    f2 e2 = {0.0f, 0.0f};
 #pragma unroll
     for (int n2 = 0; n2 < NZ; ++n2)
     {
-        z[n2] -= f2{mean, mean};
+        z[n2] -= mean2;
         if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
     }
     if (p.want_pre)                                                         // c/kaldi_mfcc.c:274-279
     {
 #pragma unroll
-        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
     }
     if (DITHER)
     {
@@ -630,9 +656,7 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
             const float xp0 = (h == 0 && n1 == 0) ? up : fa_;
             up = fa_;
             const int i0 = i00 + 64 * n2;
-            f2 y;
-            y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
-            y.y = fmaf(npre, fb_, z[n2].y) * win[i0 + 2];
+            f2 y = __builtin_elementwise_fma(npre2, f2{xp0, fb_}, z[n2]) * f2{win[i0], win[i0 + 2]};
             if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
             z[n2] = y;
         }
@@ -643,20 +667,18 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
     {
         // pre-emphasis y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0] (c/kaldi_mfcc.c:282-288), window (:291)
         const int i0 = i00 + 64 * n2;
-        const float xp0 = fa[(i0 > 0) ? i0 - 1 : 0] - mean, xp1 = fa[i0 + 1] - mean;
-        f2 y;
-        y.x = fmaf(npre, xp0, z[n2].x) * win[i0];
-        y.y = fmaf(npre, xp1, z[n2].y) * win[i0 + 2];
+        const f2 xp = f2{fa[(i0 > 0) ? i0 - 1 : 0], fa[i0 + 1]} - mean2;
+        f2 y = __builtin_elementwise_fma(npre2, xp, z[n2]) * f2{win[i0], win[i0 + 2]};
         if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
         z[n2] = y;
     }
     if (p.want_post)                                                        // c/kaldi_mfcc.c:295-301
     {
 #pragma unroll
-        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
     }
     {
-        float tot = row16_sum(e);
+        float tot = row16_sum(e2.x + e2.y);
         tot += __shfl_xor(tot, 16, 64);
         rawe = fmaxf(tot, FLT_EPSILON);
     }
@@ -697,12 +719,9 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
         const f2 ee = add_conj(zk, zp);
         const f2 tt = cmul(mi_sub_conj(zk, zp), tw2[k1 * 16 + k2]);
         const f2 a = ee + tt, b = ee - tt;                                  // 2 S[k], 2 conj S[256-k]
-        const f2 send = h ? a : b;
-        f2 recv;
-        recv.x = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(send.x)));
-        recv.y = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(send.y)));
+        f2 u, v;
+        join_swap<0>(a, b, u, v);
         const f2 w = tw3[k1 * 16 + k2];
-        const f2 u = h ? recv : a, v = h ? b : recv;
         const f2 g = h ? f2{-w.y, w.x} : w;                                 // odd group: conj W1024^(256-k) = i W1024^k
         const f2 t = cmul(v, g);
         const f2 xa = u + t, xb = u - t;
@@ -740,8 +759,9 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
     const int q00 = padx(i00);
     const int qm0 = (i00 > 0) ? padx(i00 - 1) : 0, qm = (i00 > 0) ? padx(i00 - 1) : -3;      // sample before the first one: row 0 (itself for l = 0), rows n2 > 0
     const float *win = s_tab + TABX_WIN;
+    // the lane's two samples of a row travel as one packed pair: sums, mean, pre-emphasis and window are v_pk_* instructions
     f2 z[16];
-    float sum = 0.0f;
+    f2 sum2 = {0.0f, 0.0f};
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2)
     {
@@ -750,7 +770,7 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
             f2 v = {fa[q00 + 136 * n2], fa[q00 + 136 * n2 + 4]};
             if (n2 == NZ - 1) { v.x = v0 ? v.x : 0.0f; v.y = v1 ? v.y : 0.0f; }
             z[n2] = v;
-            sum += v.x + v.y;
+            sum2 += v;
         }
         else { z[n2] = f2{0.0f, 0.0f}; }
     }
@@ -758,7 +778,7 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
     {
         // samples i00 + 128 n2 and that + 4 are the members of parity g & 1 of the Box-Muller pairs 4 n1 + (g >> 1) + 64 n2 and
         // that + 2 (the lane of the neighbouring group draws the same pairs and takes the other member)
-        sum = 0.0f;
+        sum2 = f2{0.0f, 0.0f};
 #pragma unroll
         for (int n2 = 0; n2 < NZ; ++n2)
         {
@@ -766,29 +786,30 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
             z[n2].x += dither_one(dither_bits(dkey, pr), p.dither, g & 1);
             z[n2].y += dither_one(dither_bits(dkey, pr + 2u), p.dither, g & 1);
             if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
-            sum += z[n2].x + z[n2].y;
+            sum2 += z[n2];
         }
     }
     float mean = 0.0f;
     if (p.dc0)                                                              // c/kaldi_mfcc.c:265-271
     {
-        float tot = row16_sum(sum);
+        float tot = row16_sum(sum2.x + sum2.y);
         tot += __shfl_xor(tot, 16, 64);
         tot += __shfl_xor(tot, 32, 64);
         mean = tot / (float)L;
     }
     const float npre = -p.preemph;
-    float e = 0.0f;
+    const f2 mean2 = {mean, mean}, npre2 = {npre, npre};
+    f2 e2 = {0.0f, 0.0f};
 #pragma unroll
     for (int n2 = 0; n2 < NZ; ++n2)
     {
-        z[n2] -= f2{mean, mean};
+        z[n2] -= mean2;
         if (n2 == NZ - 1) { z[n2].x = v0 ? z[n2].x : 0.0f; z[n2].y = v1 ? z[n2].y : 0.0f; }
     }
     if (p.want_pre)                                                         // c/kaldi_mfcc.c:274-279
     {
 #pragma unroll
-        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
     }
     if (DITHER)
     {
@@ -806,9 +827,7 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
             const float xp0 = (g == 0 && n1 == 0) ? up : fa_;
             up = fa_;
             const int q0 = q00 + 136 * n2;
-            f2 y;
-            y.x = fmaf(npre, xp0, z[n2].x) * win[q0];
-            y.y = fmaf(npre, fb_, z[n2].y) * win[q0 + 4];
+            f2 y = __builtin_elementwise_fma(npre2, f2{xp0, fb_}, z[n2]) * f2{win[q0], win[q0 + 4]};
             if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
             z[n2] = y;
         }
@@ -819,20 +838,18 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
     {
         // pre-emphasis y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0] (c/kaldi_mfcc.c:282-288), window (:291)
         const int q0 = q00 + 136 * n2;
-        const float xp0 = fa[(n2 == 0) ? qm0 : qm + 136 * n2] - mean, xp1 = fa[q0 + 3] - mean;
-        f2 y;
-        y.x = fmaf(npre, xp0, z[n2].x) * win[q0];
-        y.y = fmaf(npre, xp1, z[n2].y) * win[q0 + 4];
+        const f2 xp = f2{fa[(n2 == 0) ? qm0 : qm + 136 * n2], fa[q0 + 3]} - mean2;
+        f2 y = __builtin_elementwise_fma(npre2, xp, z[n2]) * f2{win[q0], win[q0 + 4]};
         if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
         z[n2] = y;
     }
     if (p.want_post)                                                        // c/kaldi_mfcc.c:295-301
     {
 #pragma unroll
-        for (int n2 = 0; n2 < NZ; ++n2) { e = fmaf(z[n2].x, z[n2].x, e); e = fmaf(z[n2].y, z[n2].y, e); }
+        for (int n2 = 0; n2 < NZ; ++n2) { e2 = __builtin_elementwise_fma(z[n2], z[n2], e2); }
     }
     {
-        float tot = row16_sum(e);
+        float tot = row16_sum(e2.x + e2.y);
         tot += __shfl_xor(tot, 16, 64);
         tot += __shfl_xor(tot, 32, 64);
         rawe = fmaxf(tot, FLT_EPSILON);
@@ -843,9 +860,8 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
 
     // untangle within the 16-lane group (as frame_power), then the two joins
     const int paddr = ((lane & 48) | ((16 - k2) & 15)) << 2;
-    const int x1addr = (lane ^ 32) << 2, x2addr = (lane ^ 16) << 2;
     const bool lane0 = (k2 == 0);
-    const bool h1 = (g & 2) != 0, h2 = (g & 1) != 0;
+    const bool h1 = (g & 2) != 0;
     const f2 *tw2 = reinterpret_cast<const f2 *>(s_tab + TABX_TW2);
     const f2 *tw3 = reinterpret_cast<const f2 *>(s_tab + TABX_TW3);
     const f2 *tw4 = reinterpret_cast<const f2 *>(s_tab + TABX_TW4);
@@ -875,21 +891,15 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
             a = f2{2.0f * z8.x, -2.0f * z8.y}; b = f2{2.0f * z8.x, 2.0f * z8.y};
         }
         // step 1 (lanes l ^ 32)
-        const f2 send1 = h1 ? a : b;
-        f2 r1;
-        r1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(x1addr, __float_as_int(send1.x)));
-        r1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(x1addr, __float_as_int(send1.y)));
+        f2 u1, v1c;
+        join_swap<1>(a, b, u1, v1c);
         const f2 w3 = tw3[k1 * 16 + k2];
-        const f2 u1 = h1 ? r1 : a, v1c = h1 ? b : r1;
         const f2 g1 = h1 ? f2{-w3.y, w3.x} : w3;                            // groups 2, 3: conj W1024^(256-k) = i W1024^k
         const f2 t1 = cmul(v1c, g1);
         const f2 xa = u1 + t1, xb = u1 - t1;
         // step 2 (lanes l ^ 16)
-        const f2 send2 = h2 ? xa : xb;
-        f2 r2;
-        r2.x = __int_as_float(__builtin_amdgcn_ds_bpermute(x2addr, __float_as_int(send2.x)));
-        r2.y = __int_as_float(__builtin_amdgcn_ds_bpermute(x2addr, __float_as_int(send2.y)));
-        const f2 u2 = h2 ? r2 : xa, v2c = h2 ? xb : r2;
+        f2 u2, v2c;
+        join_swap<0>(xa, xb, u2, v2c);
         const f2 t2 = cmul(v2c, cmul(tw4[k1 * 16 + k2], ph));
         const f2 ya = u2 + t2, yb = u2 - t2;
         const f2 qa = ya * ya, qb = yb * yb;
