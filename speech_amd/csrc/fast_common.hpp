@@ -93,7 +93,7 @@ struct FastParams {
     int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
     float dither;
     unsigned long long seed;
-    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads, 4 = mel kinds stop after the FFT, 8 = stores land in a 2 MB (L2-resident) window, 16 = every utterance reads utterance 0's audio, 32 / 64 = mel kinds stop after the power tile / after the mel contraction
+    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads, 4 = mel kinds stop after the FFT, 8 = stores land in a 2 MB (L2-resident) window, 16 = every utterance reads utterance 0's audio, 32 / 64 = mel kinds stop after the power tile / after the mel contraction, 256 = mel kinds load their audio through registers (no buffer_load ... lds)
     const float *tab;
     // mel kinds
     const float *melw, *mat2, *aux;
@@ -301,10 +301,23 @@ __device__ __forceinline__ f2 spec_log2(float qa, float qb)
 // Interior quads use raw buffer loads: one sample per lane per instruction, lane offset in one VGPR, the step in an
 // SGPR, and the descriptor's range check instead of a per-lane bound test.
 template <bool PADX = false>
-__device__ __forceinline__ void load_span(float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int lane)
+__device__ __forceinline__ void load_span(float *s_aud, const float *xu, const short *xu16, long long s0, int need, long long N, int lane, const int dma_floats = 0)
 {
     constexpr int ROW = PADX ? 68 : 64;                                     // floats between the rows of 64 samples (padx)
     const int lofs = PADX ? lane + 2 * (lane >> 5) : lane;
+    if (!PADX && !xu16 && ((need + 255) & ~255) <= dma_floats && s0 >= 0 && s0 + need <= N)
+    {
+        // float audio straight into the slice: buffer_load_dwordx4 ... lds (gfx950) moves 1 KB per wave-instruction from
+        // memory into LDS without passing through registers -- 4 instructions for a quad's 880 samples instead of 14 loads
+        // and 14 ds_write_b32.  dma_floats = the slice's room in whole instructions (a multiple of 256 floats; a span that needs more takes the
+        // register path below); samples past `need` arrive as 0.
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu + s0), 0, need * 4, BUF_FLAGS);
+        for (int c = 0; 256 * c < need; ++c)
+        {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_aud + 256 * c), 16, lane * 16, 1024 * c, 0, 0);
+        }
+        return;
+    }
     if (s0 >= 0 && s0 + need <= N)
     {
         const int nit = (need + 63) >> 6;

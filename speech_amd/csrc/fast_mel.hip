@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NTM, XW ? 4 : 6) void fast_mel_kernel(const FastPar
     {
         const long long w0 = (long long)tile.frame0 + fbase + fq;
         const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
-        if (!(p.ablate & 2)) load_span<XW>(s_aud, p.X + ((p.ablate & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane);
+        if (!(p.ablate & 2)) load_span<XW>(s_aud, p.X + ((p.ablate & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane, (p.ablate & 256) ? 0 : (p.ws & ~255));
     }
     __syncthreads();
 
