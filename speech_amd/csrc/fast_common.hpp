@@ -90,6 +90,7 @@ struct FastParams {
     int L, stp, D, span, ws;            // span: floats of a quad's audio, rounded up to 64; ws: floats of a wave's LDS slice (>= span, TR_WAVE)
     int snip_edges, dc0, want_pre, want_post;
     float preemph;                      // 0 when pre-emphasis is off
+    float invL;                         // 1 / L: the frame mean is sum * invL (an IEEE division is 10 instructions; the lanes' tree sum already rounds otherwise than the reference's running sum)
     int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
     float dither;
     unsigned long long seed;
@@ -491,7 +492,7 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
         }
     }
     float mean = 0.0f;
-    if (p.dc0) { mean = row16_sum(sum2.x + sum2.y) / (float)L; }            // c/kaldi_mfcc.c:265-271
+    if (p.dc0) { mean = row16_sum(sum2.x + sum2.y) * p.invL; }             // c/kaldi_mfcc.c:265-271
     const f2 mean2 = {mean, mean};
     const float npre = -p.preemph;
     const f2 *win = reinterpret_cast<const f2 *>(s_tab + TAB_WIN);
@@ -636,7 +637,7 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
     {
         float tot = row16_sum(sum2.x + sum2.y);
         tot += __shfl_xor(tot, 16, 64);
-        mean = tot / (float)L;
+        mean = tot * p.invL;
     }
     const float npre = -p.preemph;
     const f2 mean2 = {mean, mean}, npre2 = {npre, npre};
@@ -808,7 +809,7 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
         float tot = row16_sum(sum2.x + sum2.y);
         tot += __shfl_xor(tot, 16, 64);
         tot += __shfl_xor(tot, 32, 64);
-        mean = tot / (float)L;
+        mean = tot * p.invL;
     }
     const float npre = -p.preemph;
     const f2 mean2 = {mean, mean}, npre2 = {npre, npre};
@@ -964,7 +965,7 @@ __device__ __forceinline__ void frame_power_pair(const float *fa, const int bofs
         }
     }
     f2 mean2 = {0.0f, 0.0f};
-    if (p.dc0) { mean2 = f2{row16_sum(sum2.x) / (float)L, row16_sum(sum2.y) / (float)L}; }      // c/kaldi_mfcc.c:265-271, per frame
+    if (p.dc0) { mean2 = f2{row16_sum(sum2.x), row16_sum(sum2.y)} * p.invL; }      // c/kaldi_mfcc.c:265-271, per frame
     const float npre = -p.preemph;
     const f2 npre2 = {npre, npre};
     const f2 *win2 = reinterpret_cast<const f2 *>(s_tab + TAB_WIN);         // (w[n], w[n]) pairs in this mode

@@ -253,6 +253,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, hipStr
     memset(&p, 0, sizeof(p));
     p.X = fp.X; p.X16 = fp.X16; p.Y = fp.Y; p.utts = fp.utts; p.tiles = fp.tiles; p.ntiles = fp.ntiles;
     p.L = fp.L; p.stp = fp.stp; p.D = fp.D;
+    p.invL = 1.0f / (float)fp.L;
     const FastGeom &g = t->geom;
     p.span = (int)g.span; p.ws = (int)g.ws; p.m2 = (int)g.m2;
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
