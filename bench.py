@@ -56,6 +56,7 @@ WORKLOADS = {
     "fbank80_48kHz_1000x10s": dict(kind="fbank", opts=dict(FBANK80, sr=48000.0, hif=24000.0), lens="fixed", nutt=1000, secs=10.0, sr=48000.0),
     "mfcc13_48kHz_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=48000.0, hif=24000.0), lens="fixed", nutt=1000, secs=10.0, sr=48000.0),
     "fbank80_44kHz_1000x10s": dict(kind="fbank", opts=dict(FBANK80, sr=44100.0, hif=22050.0), lens="fixed", nutt=1000, secs=10.0, sr=44100.0),
+    "mfcc13_48kHz_dither1_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=48000.0, hif=24000.0, dither=1.0), lens="fixed", nutt=1000, secs=10.0, sr=48000.0),
     "mfcc13_44kHz_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=44100.0, hif=22050.0), lens="fixed", nutt=1000, secs=10.0, sr=44100.0),
     "spectrogram_48kHz_1000x10s": dict(kind="spectrogram", opts=dict(sr=48000.0, **FRONT), lens="fixed", nutt=1000, secs=10.0, sr=48000.0),
     "mfcc13_22kHz_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, sr=22050.0, hif=11025.0), lens="fixed", nutt=1000, secs=10.0, sr=22050.0),

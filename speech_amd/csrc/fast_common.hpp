@@ -70,13 +70,15 @@ constexpr int PP = 258;                 // pitch of the TILE x 257 power tile (=
 // 1024-point plans ("wide": one frame on 32 lanes, frame_power_wide): win[1024] | tw1 | tw2 | tw3[8][16] complex = W1024^(k2 + 16 k1)
 constexpr int TABW_WIN = 0, TABW_TW1 = 1024, TABW_TW2 = 1536, TABW_TW3 = 1792, TABW_FLOATS = 2048;
 constexpr int PPW = 514;                // pitch of the 16 x 513 power tile of the wide mode (= 2 mod 32)
-// 2048-point plans ("xwide": one frame on the wave's 64 lanes, frame_power_xwide): win[2048, padded] | tw1 | tw2 | tw3[9][16] complex =
-// W1024^(k2 + 16 k1) | tw4[9][16] complex = W2048^(k2 + 16 k1)   (row k1 = 8 serves bin 128 of lane k2 = 0).
+// 2048-point plans ("xwide": one frame on the wave's 64 lanes, frame_power_xwide): tw1 | tw2 | tw3[9][16] complex = W1024^(k2 + 16 k1)
+// | tw4[9][16] complex = W2048^(k2 + 16 k1) (row k1 = 8 serves bin 128 of lane k2 = 0) | win[2048, padded].
 // A lane of that mode reads samples (and window factors) 8 apart, which in a dense array puts 32 lanes on 8 banks; the
 // audio slice and the window table therefore carry 2 floats of padding after every 32 (sample i lives at padx(i)):
 // 8 a + 2 b + g (a, b = 0..3, g = 0..1) are 32 different banks, and the rows of 64 samples the loads park stay conflict-free.
 __host__ __device__ constexpr int padx(int i) { return i + 2 * (i >> 5); }
-constexpr int TABX_WIN = 0, TABX_TW1 = 2176, TABX_TW2 = 2688, TABX_TW3 = 2944, TABX_TW4 = 3232, TABX_FLOATS = 3520;
+// The window comes LAST: the mel kernels stage only the twiddles (TABX_TWF floats) in LDS and read the window through L1 (8.7 KB
+// less LDS per workgroup is what lets three of them share a CU); the spectrogram kernel stages the whole table.
+constexpr int TABX_TW1 = 0, TABX_TW2 = 512, TABX_TW3 = 768, TABX_TW4 = 1056, TABX_TWF = 1344, TABX_WIN = 1344, TABX_FLOATS = 3520;
 constexpr int PPX = 1026;               // pitch of the 8 x 1025 power tile of the xwide mode (= 2 mod 32)
 constexpr unsigned BUF_FLAGS = 0x00020000u;   // word 3 of a raw buffer descriptor on gfx9/CDNA: 32-bit data format
 
@@ -760,7 +762,9 @@ __device__ __forceinline__ void frame_power_wide(const float *fa, const float *s
 //   group 0: pa = k,       pb = 1024-k        group 1: pa = 512-k,   pb = 512+k
 //   group 2: pa = 256-k,   pb = 768+k         group 3: pa = 256+k,   pb = 768-k
 // (k = 0: groups 1 and 3 repeat bins 512 and 256 / 768; k = 128: groups 2 and 3 repeat groups 0 and 1.)
-template <int NZ, bool HALF, bool DITHER>
+// WING: the window factors come from the plan's table in memory (p.tab, L1-resident) instead of from LDS; they are requested
+// right after the samples and arrive during the mean reduction.
+template <int NZ, bool HALF, bool DITHER, bool WING = false>
 __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *s_tab, float *s_tr, const int lane, const FastParams &p,
                                                   const unsigned long long dkey, float (&pa)[9], float (&pb)[9], float &rawe)
 {
@@ -773,6 +777,17 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
     const int q00 = padx(i00);
     const int qm0 = (i00 > 0) ? padx(i00 - 1) : 0, qm = (i00 > 0) ? padx(i00 - 1) : -3;      // sample before the first one: row 0 (itself for l = 0), rows n2 > 0
     const float *win = s_tab + TABX_WIN;
+    f2 wg[WING ? NZ : 1];
+    if (WING)
+    {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tab + TABX_WIN), 0, (TABX_FLOATS - TABX_WIN) * 4, BUF_FLAGS);
+#pragma unroll
+        for (int n2 = 0; n2 < NZ; ++n2)
+        {
+            wg[n2].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, q00 * 4, 136 * 4 * n2, 0));
+            wg[n2].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, q00 * 4, 136 * 4 * n2 + 16, 0));
+        }
+    }
     // the lane's two samples of a row travel as one packed pair: sums, mean, pre-emphasis and window are v_pk_* instructions
     f2 z[16];
     f2 sum2 = {0.0f, 0.0f};
@@ -841,7 +856,7 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
             const float xp0 = (g == 0 && n1 == 0) ? up : fa_;
             up = fa_;
             const int q0 = q00 + 136 * n2;
-            f2 y = __builtin_elementwise_fma(npre2, f2{xp0, fb_}, z[n2]) * f2{win[q0], win[q0 + 4]};
+            f2 y = __builtin_elementwise_fma(npre2, f2{xp0, fb_}, z[n2]) * (WING ? wg[n2] : f2{win[q0], win[q0 + 4]});
             if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
             z[n2] = y;
         }
@@ -853,7 +868,7 @@ __device__ __forceinline__ void frame_power_xwide(const float *fa, const float *
         // pre-emphasis y[l] = d[l] - p d[l-1], y[0] = d[0] - p d[0] (c/kaldi_mfcc.c:282-288), window (:291)
         const int q0 = q00 + 136 * n2;
         const f2 xp = f2{fa[(n2 == 0) ? qm0 : qm + 136 * n2], fa[q0 + 3]} - mean2;
-        f2 y = __builtin_elementwise_fma(npre2, xp, z[n2]) * f2{win[q0], win[q0 + 4]};
+        f2 y = __builtin_elementwise_fma(npre2, xp, z[n2]) * (WING ? wg[n2] : f2{win[q0], win[q0 + 4]});
         if (n2 == NZ - 1) { y.x = v0 ? y.x : 0.0f; y.y = v1 ? y.y : 0.0f; }
         z[n2] = y;
     }

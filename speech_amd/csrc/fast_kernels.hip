@@ -31,7 +31,7 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     g.fw = g.xwide ? 1 : (g.wide ? 2 : (g.pair ? 2 * QF : QF));
     g.nz = g.xwide ? (int)((L + 127u) / 128u) : (g.wide ? (int)((L + 63u) / 64u) : (g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u)));
     const size_t F = nfft / 2u + 1u, rows = (g.xwide ? 128u : (g.wide ? 64u : (g.pair ? 16u : 32u))) * (size_t)g.nz;
-    const size_t tabf = g.xwide ? (size_t)TABX_FLOATS : (g.wide ? (size_t)TABW_FLOATS : (size_t)TAB_FLOATS);
+    const size_t tabf = g.xwide ? (o.kind == SPEECH_SPECTROGRAM ? (size_t)TABX_FLOATS : (size_t)TABX_TWF) : (g.wide ? (size_t)TABW_FLOATS : (size_t)TAB_FLOATS);
     // two workgroups per CU are what the 2048-point kernels are built for (128 VGPRs); the others stay below 64 KB
     const size_t lds_max = g.xwide ? (size_t)100 * 1024u : (size_t)64 * 1024u;   // above 80 KB (long frames with many mel bins): one workgroup per CU
     g.span = (((size_t)g.fw - 1u) * stp + rows + 63u) & ~(size_t)63;        // whole 64-lane load instructions fit the slice
@@ -68,7 +68,7 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     // the second contraction's matrix (mfcc: lifter x DCT, K2 x Cp; plp: IDFT bases, K2 x 16) rides in LDS behind the
     // tables when that does not cost a resident workgroup; otherwise the kernel reads it from global memory (L2)
     const size_t m2 = (o.kind == SPEECH_MFCC) ? cols * 16u * ((o.C + 15u) / 16u) : (o.kind == SPEECH_PLP ? cols * 16u : 0u);
-    const size_t m2_max = !g.xwide ? (size_t)LDS_3_PER_CU : (g.lds <= 80u * 1024u ? (size_t)80 * 1024u : lds_max);      // 2048-point plans: two per CU up to 80 KB
+    const size_t m2_max = (!g.xwide || g.lds <= (size_t)LDS_3_PER_CU) ? (size_t)LDS_3_PER_CU : (g.lds <= 80u * 1024u ? (size_t)80 * 1024u : lds_max);      // 2048-point plans: three per CU where the frame is short enough, else two up to 80 KB
     if (g.ok && m2 > 0u && g.lds + m2 * sizeof(float) <= m2_max) { g.m2 = m2; g.lds += m2 * sizeof(float); }
     return g;
 }

@@ -106,10 +106,10 @@ __device__ __forceinline__ f32x4 mfma_tile_pre(const float *arow, const float (&
 // WIDE (1024-point plans): 2 frames per wave, 32 lanes each (frame_power_wide), 16 frames per tile, a 16 x 514 power
 // tile; NZ counts rows of 64 samples.
 // XW (2048-point plans): 1 frame per wave (frame_power_xwide), 8 frames per tile, an 8 x 1026 power tile that fills half
-// of a 16-row matrix-core tile (rows 8..15 repeat rows 0..7 and are dropped); NZ counts rows of 128 samples.  The slices
-// (up to 8 KB each) leave room for two workgroups per CU, so the kernel may use 128 VGPRs.
+// of a 16-row matrix-core tile (rows 8..15 repeat rows 0..7 and are dropped); NZ counts rows of 128 samples.  Only the twiddles
+// are staged in LDS (the window is read through L1), so that at 48 kHz / 25 ms three workgroups still share a CU.
 template <int NZ, int KIND, int P, bool DITHER, bool PAIR, bool WIDE = false, bool XW = false>
-__global__ __launch_bounds__(NTM, XW ? 4 : 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs
+__global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(const FastParams p)      // 6 waves per SIMD = 3 workgroups per CU: at most 80 VGPRs (2048-point frames above 1280 samples: LDS holds two workgroups, 128 VGPRs)
 {
     static_assert(!(PAIR && WIDE) && !(XW && (PAIR || WIDE)), "one mode at a time");
     constexpr int FWK = XW ? 1 : (WIDE ? 2 : (PAIR ? 2 * QF : QF));         // frames per wave
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NTM, XW ? 4 : 6) void fast_mel_kernel(const FastPar
     // per 32 or 16 frames, one barrier pair less per sub-tile, and the tail's latency (the other six waves wait for it) paid
     // once per 128 frames (64 -> 128: -2 %; both frames of a lane pair in packed-f32 registers on one wave: no better)
     constexpr int NSUB = (KIND == SPEECH_PLP) ? PLP_TAIL_FRAMES / TILEK : 1;
-    constexpr int TABK = XW ? TABX_FLOATS : (WIDE ? TABW_FLOATS : TAB_FLOATS);     // floats of tables in front of the slices
+    constexpr int TABK = XW ? TABX_TWF : (WIDE ? TABW_FLOATS : TAB_FLOATS);        // floats of tables in front of the slices (2048-point plans: the twiddles; the window stays in memory)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     int lane = tid & 63;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NTM, XW ? 4 : 6) void fast_mel_kernel(const FastPar
     {
         const unsigned long long dkey = DITHER ? dither_frame_key(mix64(p.seed ^ ((unsigned long long)tile.uid << 32)),
                                                                   (unsigned long long)((long long)tile.frame0 + fbase + fq)) : 0ull;
-        frame_power_xwide<NZ, true, DITHER>(s_aud, s_tab_l, s_tr, lane, p, dkey, pa, pb, rawe);
+        frame_power_xwide<NZ, true, DITHER, true>(s_aud, s_tab_l, s_tr, lane, p, dkey, pa, pb, rawe);
     }
     else if (nfr > 0 && WIDE)
     {
