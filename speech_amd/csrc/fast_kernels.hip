@@ -27,7 +27,8 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     g.pair = (nfft == (size_t)NFFT / 2u);
     g.wide = (nfft == 2u * (size_t)NFFT);
     g.xwide = (nfft == 4u * (size_t)NFFT);
-    if ((stp > 1024u || (stp & 1u)) && !g.xwide) { return g; }            // a 2048-point frame starts its wave's slice: any shift; the others read sample pairs
+    if (stp > 1024u && !g.xwide) { return g; }
+    if ((stp & 1u) && !g.xwide && !g.wide) { return g; }                    // 1024- and 2048-point frames are read sample by sample: any shift; the others read aligned sample pairs
     g.fw = g.xwide ? 1 : (g.wide ? 2 : (g.pair ? 2 * QF : QF));
     g.nz = g.xwide ? (int)((L + 127u) / 128u) : (g.wide ? (int)((L + 63u) / 64u) : (g.pair ? (int)((L + 15u) / 16u) : (int)((L + 31u) / 32u)));
     const size_t F = nfft / 2u + 1u, rows = (g.xwide ? 128u : (g.wide ? 64u : (g.pair ? 16u : 32u))) * (size_t)g.nz;

@@ -80,6 +80,8 @@ for j, (sr, snip, dc0, rawe) in enumerate(((22050.0, 1, 1, 1), (32000.0, 0, 0, 0
     _add("spectrogram", [9000, 3000, 700, 12001][j], 660 + j, sr=sr, snip=snip, dc0=dc0, raw_energy=rawe,
          win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j])
 _add("mfcc", 1024, 650, sr=16000.0, fl=64.0, fs=16.0)            # L=1024 == nfft, one frame
+_add("mfcc", 20000, 652, sr=32000.0, hif=16000.0, fs=10.03125, snip=0)      # stp=321 (odd) on a 1024-point plan: tuned (frames are read sample by sample)
+_add("spectrogram", 20000, 653, sr=22050.0, fs=10.03)                      # stp=221 (odd)
 # 2048-point frames on the tuned kernels (one frame per wave; 44.1 / 48 kHz at 25 ms, odd frame shifts included): every
 # switch, several 8- / 16- / 128-frame tiles, short signals with reflected edges
 for i, (kind, extra) in enumerate((("fbank", dict(B=80)), ("fbank", dict(B=40, amp=1, use_energy=1)), ("mfcc", dict(B=23, C=13)),

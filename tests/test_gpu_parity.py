@@ -495,7 +495,7 @@ def test_which_plans_run_on_the_tuned_kernels():
              ("fbank", dict(sr=22050.0, hif=11025.0, B=80)), ("mfcc", dict(sr=32000.0, hif=16000.0)), ("plp", dict(sr=24000.0, hif=12000.0)), ("mfcc", dict(fl=64.0, fs=20.0)), ("spectrogram", dict(sr=22050.0)), ("spectrogram", dict(sr=32000.0)),
              ("mfcc", dict(sr=22050.0, hif=11025.0, dither=1.0)), ("spectrogram", dict(sr=22050.0, dither=1.0)),
              ("spectrogram", dict(sr=44100.0)), ("fbank", dict(sr=44100.0, hif=22050.0)), ("mfcc", dict(sr=48000.0, hif=24000.0, dither=1.0)), ("plp", dict(sr=48000.0, hif=24000.0)),
-             ("fbank", dict(fl=128.0, fs=40.0, B=128))]
+             ("fbank", dict(fl=128.0, fs=40.0, B=128)), ("mfcc", dict(sr=32000.0, hif=16000.0, fs=10.03125)), ("spectrogram", dict(sr=22050.0, fs=10.03))]
     generic = [("mfcc", dict(sr=4000.0, hif=2000.0, B=15)), ("spectrogram", dict(sr=96000.0)), ("mfcc", dict(sr=16100.0)),
                ("fbank", dict(sr=96000.0, hif=22050.0)),
                ("plp", dict(order=16)), ("fbank", dict(B=129)), ("mfcc", dict(fs=10.0625)), ("fbank", dict(B=1))]
