@@ -105,6 +105,13 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
         // frame start: c/kaldi_mfcc.c:81-82,216-240
         const long long start = p.snip_edges ? w * p.stp : (long long)(p.stp / 2) - (long long)(L / 2) + w * p.stp;
         __syncthreads();
+        if (start >= 0 && start + L <= N)                                   // (uniform) an interior frame: no reflection, 32-bit indexing
+        {
+            const T *xf = x + start;
+            const short *xf16 = x16 ? x16 + start : nullptr;
+            for (int l = tid; l < nfft; l += NTH) { re[l] = (l < L) ? (xf16 ? (T)xf16[l] : xf[l]) : (T)0; }
+        }
+        else
         for (int l = tid; l < nfft; l += NTH)
         {
             T v = (T)0;
@@ -208,16 +215,18 @@ __global__ __launch_bounds__(NTH) void generic_frames_kernel(const FrameParams<T
             __syncthreads();
             half = 2;
         }
-        for (; half < n2; half <<= 2)
+        int lh = (lg2 & 1) ? 1 : 0;                                         // log2(half)
+        for (; half < n2; half <<= 2, lh += 2)
         {
-            const int t1 = nfft / (2 * half), t2 = nfft / (4 * half);
+            // twiddle strides nfft / (2 half) and nfft / (4 half) are powers of two: shifts, not 32-bit multiplies (quarter rate)
+            const int sh1 = p.log2n - lh - 1, sh2 = sh1 - 1;
             for (int i = tid; i < n2 / 4; i += NTH)
             {
                 const int k = i & (half - 1);
                 const int a = ((i - k) << 2) + k, b = a + half, c = b + half, d = c + half;
-                const T c1 = twr[k * t1], s1 = twi[k * t1];
-                const T c2 = twr[k * t2], s2 = twi[k * t2];
-                const T c3 = twr[(k + half) * t2], s3 = twi[(k + half) * t2];
+                const T c1 = twr[k << sh1], s1 = twi[k << sh1];
+                const T c2 = twr[k << sh2], s2 = twi[k << sh2];
+                const T c3 = twr[(k + half) << sh2], s3 = twi[(k + half) << sh2];
                 T ar = zr[a], ai = zi[a], br = zr[b], bi = zi[b], cr = zr[c], ci = zi[c], dr = zr[d], di = zi[d];
                 // stage `half`
                 T tr = br * c1 - bi * s1, ti = br * s1 + bi * c1;
