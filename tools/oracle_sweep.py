@@ -7,6 +7,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import signals, oracle_lib as O, np_truth as T
 from compare import check_parity
+import compare
 from speech_amd import api
 WINDOWS = ("povey", "hamming", "hann", "rectangular", "blackman")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
@@ -56,5 +57,5 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
     _, ref_fast = O.run(kind, x, single=single, exact=False, **o)
     ok, e_go, e_gt, e_ot = check_parity(kind, o, got, ref, truth, tol=(1e-5 if kind == "spectrogram" else 1e-4) if single else 1e-9, oracle_fast=ref_fast, max_margin=3.0)
     if not ok or not np.isfinite(got).all():
-        bad += 1; print("PARITY", kind, "single" if single else "double", o, N, "hip-oracle %.3g hip-f64 %.3g oracle-f64 %.3g" % (e_go, e_gt, e_ot), flush=True)
+        bad += 1; print("PARITY", kind, "single" if single else "double", o, N, "hip-oracle %.3g hip-f64 %.3g oracle-f64 %.3g rms ratio %.3g tuned %s" % (e_go, e_gt, e_ot, compare.PARITY_LOG[-1][6], api.Plan(kind, **{k: v for k, v in o.items() if k != "mn0"}).tuned if single else False), flush=True)
 print("sets", n, "bad", bad)
