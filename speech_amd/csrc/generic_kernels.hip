@@ -15,7 +15,16 @@ namespace {
 
 template <typename T> struct M;
 template <> struct M<float> {
-    static __device__ __forceinline__ float log(float x) { return logf(x); }
+    // natural log of a positive normal float (every caller floors its argument at FLT_EPSILON): exponent and mantissa split,
+    // so that the hardware log2 (1 ulp of its RESULT) only sees [0.5, 1) and the one rounding left is the result's own.
+    // The library logf measured ~1 ulp at |log| ~ 20, i.e. 2e-6 on a log-power value: twice the rms noise of the whole
+    // float32 pipeline on the CPU (tools/noise_check.py); this form is the tuned kernels' (fast_common.hpp, pos_log).
+    static __device__ __forceinline__ float log(float x)
+    {
+        const float m = __builtin_amdgcn_frexp_mantf(x);
+        const float e = (float)__builtin_amdgcn_frexp_expf(x);
+        return fmaf(e, 0.69314718055994530942f, __log2f(m) * 0.69314718055994530942f);
+    }
     static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
     static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
     static __device__ __forceinline__ float cos(float x) { return cosf(x); }

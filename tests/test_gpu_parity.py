@@ -193,12 +193,9 @@ def test_tuned_and_generic_kernels_agree():
             assert plan.tuned == (fg == 0), (kind, fg)
             outs.append(Y.cpu().numpy().reshape(-1, plan.D))
         for fg, got in enumerate(outs):
-            # the generic kernels (coverage path: any frame size, f64) are a plain radix-2 pipeline, a little noisier than the
-            # tuned ones: their rms noise may reach 1.5 x the CPU arithmetic's (measured 1.25 on this input), the tuned
-            # kernels keep the suite's 1.25.  On 2048-point frames the generic spectrogram measured 1.65 (ten radix-2 stages
-            # with float twiddles; the tuned 2048-point kernels: within 1.25 like the rest): 1.75 there
-            gm = 1.75 if (kind == "spectrogram" and o.get("sr", 16000.0) >= 44100.0) else 1.5
-            ok, msg = _parity(kind, o, x, got, margin=gm if fg else None)
+            # both keep the suite's margin of 1.25 on the rms noise level (the generic kernels did not until their float log was
+            # split into exponent and mantissa like the tuned kernels': the library logf alone doubled the noise of a log-power value)
+            ok, msg = _parity(kind, o, x, got)
             assert ok, (kind, fg, msg)
         # mutual bound: 2e-4, or twice the distance of the float32 CPU oracle from a float64 statement of the same
         # algorithm where that is larger (this tonal signal puts weak bins at the float32 FFT noise floor; the 80-bin
