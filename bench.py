@@ -7,9 +7,13 @@
 One "step" is one pass of the per-frame pipeline (c/kaldi_fbank.c:208-351) over one resident batch of synthetic 16 kHz
 audio.  The headline workload is the one BASELINE.json's metric is quoted on, configs[2]: kaldi_fbank, 80 log-mel bins,
 over a ragged batch of 100,000 utterances of 1-30 s per GPU (99 GB of audio + 50 GB of features, resident in HBM).
+The audio is the synthetic corpus of SURVEY.md 8(d) (integer counter-based generator, speech_batch_synth_audio: generated on
+the device, bit-identical to the host statement, so the CPU legs regenerate the very samples instead of copying them back).
 Utterances are independent, so ranks shard them with no collective ("weak" scaling: every rank owns 100,000 utterances,
 its part of an LPT assignment of N x 100,000); the only cross-rank steps are the barrier, the max over ranks of the
-elapsed time and the gather of the per-GPU figures.  Started WITHOUT a launcher and with --gpus N > 1 it starts the N
+elapsed time and the gather of the per-GPU figures -- bookkeeping on CPU tensors over gloo, in rehearsals and real runs alike
+(RCCL is not linked: nothing on the data path has an exchange step).  After the timed region the output it left is CHECKED
+(finite, last-bin quirk, three utterances against the CPU oracle) and the verdict is part of the line.  Started WITHOUT a launcher and with --gpus N > 1 it starts the N
 ranks itself (fresh child processes, before the parent touches any GPU).  Rank 0 prints ONE JSON line; DESIGN.md
 section "Measurement" explains every field.
 """
@@ -65,35 +69,40 @@ HEADLINE = "fbank80_100k_ragged_1-30s"
 HEADLINE_TEXT = ("kaldi_fbank, 80 log-mel bins, on a ragged batch of 100,000 16 kHz utterances of 1-30 s per GPU, 25/10 ms frames, "
                  "512-pt FFT (BASELINE.json configs[2])")
 WAVE_AUDIO_S = 1.0e6           # corpus leg: audio-seconds per wave (64 GB of float32 audio + 16 GB of hires features in HBM)
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r2_counters.json")       # written by tools/pmc_to_json.py from rocprofv3 --pmc passes
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r3_counters.json")       # written by tools/pmc_to_json.py from rocprofv3 --pmc passes
+CORPUS_SEED = 0x5EED2026       # master seed of the synthetic corpus
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 vector (and f32 matrix) peak
+ALG_FLOP_PER_FRAME = {"spectrogram": 2000 + 11520 + 800, "fbank": 2000 + 11520 + 800 + 1000, "mfcc": 2000 + 11520 + 800 + 1000,
+                      "plp": 2000 + 11520 + 800 + 1000}     # front end + real FFT-512 (2.5 n log2 n) + power + sparse mel; the DCT is added per plan (2 B C)
 
 
 def lengths(w, rank, world, nutt):
+    """(sample counts, corpus numbers) of this rank's utterances.  The corpus number keys the synthetic generator (and the
+    dither), so an utterance's audio does not depend on which rank holds it."""
     if w["lens"] == "fixed":
-        return np.full(nutt, int(w["secs"] * w.get("sr", SR)), dtype=np.uint64)
+        return np.full(nutt, int(w["secs"] * w.get("sr", SR)), dtype=np.uint64), np.arange(rank * nutt, (rank + 1) * nutt, dtype=np.uint64)
     # 1-30 s, SURVEY.md 8(d) config 3.  N ranks: one list of N x nutt lengths, dealt to the ranks by api.shard_utterances
     # (longest first to the least loaded rank; no utterance is split) -- every rank derives the same assignment by itself
-    rng = np.random.default_rng(0x5EED2026)
+    rng = np.random.default_rng(CORPUS_SEED)
     allens = rng.integers(16000, 480001, size=nutt * world).astype(np.int64)
     if world == 1:
-        return allens.astype(np.uint64)
+        return allens.astype(np.uint64), np.arange(nutt, dtype=np.uint64)
     from speech_amd import api
-    return allens[api.shard_utterances(allens, world)[rank]].astype(np.uint64)
+    mine = api.shard_utterances(allens, world)[rank]
+    return allens[mine].astype(np.uint64), mine.astype(np.uint64)
 
 
-def synth_audio(total, device, seed):
-    """int16-scale noise plus slow tones, generated on the device (nothing crosses PCIe)."""
-    import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    x = torch.empty(total, device=device, dtype=torch.float32)
-    chunk = 1 << 26
-    for i in range(0, total, chunk):
-        n = min(chunk, total - i)
-        t = (torch.arange(i, i + n, device=device, dtype=torch.int64) % 16000).to(torch.float32)    # whole-Hz tones repeat every second: exact phase however long the array
-        x[i:i + n] = (1000.0 * torch.randn(n, device=device, generator=g)
-                      + 3000.0 * torch.sin(t * (2 * np.pi * 440.0 / SR)) + 1500.0 * torch.sin(t * (2 * np.pi * 2750.0 / SR)))
-    return x
+def host_audio(ids, lens):
+    """the same samples on the host: speech_synth_audio_host, the C statement of the generator (bit-identical to the device's,
+    tests/test_corpus.py) -- nothing is copied back from the GPU for the CPU legs"""
+    from speech_amd import _lib
+    lib = _lib.load()
+    out = []
+    for u, n in zip(ids, lens):
+        a = np.empty(int(n), dtype=np.int16)
+        assert lib.speech_synth_audio_host(CORPUS_SEED, int(u), int(n), a.ctypes.data_as(C.POINTER(C.c_short))) == 0
+        out.append(a)
+    return out
 
 
 class Work:
@@ -106,12 +115,11 @@ class Work:
         self.opts = w["opts"]
         self.sr = w.get("sr", SR)
         self.plan = api.Plan(w["kind"], device=device.index, **w["opts"])
-        self.lens = lengths(w, rank, world, nutt or w["nutt"])
+        self.lens, self.ids = lengths(w, rank, world, nutt or w["nutt"])
         self.batch = api.Batch(self.plan, self.lens)
-        self.X = synth_audio(self.batch.total_samples, device, 1234 + rank)
         self.pcm16 = bool(w.get("pcm16"))
-        if self.pcm16:
-            self.X = self.X.round().clamp(-32767, 32767).to(torch.int16)
+        self.X = torch.empty(self.batch.total_samples, device=device, dtype=torch.int16 if self.pcm16 else torch.float32)
+        self.batch.synth_audio(self.X, seed=CORPUS_SEED, ids=self.ids, stream=torch.cuda.current_stream().cuda_stream)
         self.Y = torch.zeros(self.batch.total_out, device=device, dtype=torch.float32)
         self.audio_s = float(self.batch.total_samples) / self.sr
         # algorithmic bytes per launch: read every sample once, write every feature once
@@ -156,12 +164,16 @@ def cpu_baseline(work, budget_s=10.0):
     kind_id = {"spectrogram": 0, "fbank": 1, "mfcc": 2, "plp": 3}[work.kind]
     pz, pf = C.POINTER(C.c_size_t), C.POINTER(C.c_float)
 
+    cache = {}
+
     def run(nutt):
         lens = work.lens[:nutt].astype(np.uint64)
         xo = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
         nf = work.batch.n_frames[:nutt].astype(np.uint64)
         yo = np.concatenate([[0], np.cumsum(nf * work.plan.D)[:-1]]).astype(np.uint64)
-        X = work.X[:int(lens.sum())].cpu().numpy()
+        if nutt not in cache:                                            # regenerated on the host, once, outside the timed call
+            cache[nutt] = np.concatenate(host_audio(work.ids[:nutt], lens)).astype(np.float32)
+        X = cache[nutt]
         Y = np.zeros(int((nf * work.plan.D).sum()), dtype=np.float32)
         t0 = time.perf_counter()
         used = lib.oracle_batch_s(kind_id, nutt, X.ctypes.data_as(pf), xo.ctypes.data_as(pz), lens.ctypes.data_as(pz), Y.ctypes.data_as(pf),
@@ -181,7 +193,7 @@ def cpu_baseline(work, budget_s=10.0):
         tot_dt += dt; tot_secs += secs; passes += 1
     return {"value": tot_secs / tot_dt, "unit": "audio-s/s", "cores": used, "kind": "port",
             "sample": "%d passes over the first %d utterances (%.0f audio-s in all) of %s, oracle/liboracle_native.so (C restatement of the "
-                      "reference's per-utterance call, float FFT, OpenMP over utterances), %.1f s wall"
+                      "reference's per-utterance call, float FFT, OpenMP over utterances) on the same samples regenerated on the host, %.1f s wall"
                       % (passes, n, tot_secs, work.name, tot_dt)}
 
 
@@ -224,7 +236,7 @@ def pcie_inclusive(work, device, nutt=64):
     lens = work.lens[:nutt]
     b = api.Batch(work.plan, lens)
     Xh = torch.empty(b.total_samples, dtype=torch.float32).pin_memory()
-    Xh.copy_(work.X[:b.total_samples].cpu())
+    Xh.copy_(torch.from_numpy(np.concatenate(host_audio(work.ids[:nutt], lens)).astype(np.float32)))
     Yh = torch.empty(b.total_out, dtype=torch.float32).pin_memory()
     Xd = torch.empty(b.total_samples, device=device)
     Yd = torch.empty(b.total_out, device=device)
@@ -258,22 +270,98 @@ def corpus_waves(device, hours, steps_note=None):
 
 def utilisation(workload):
     """VALU / MFMA utilisation and HBM traffic of the workload's dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r2_counters.json, produced by tools/profile_round.sh + tools/pmc_to_json.py on the same bench command)."""
+    (profiles/r3_counters.json, produced by tools/gpu_prof.sh + tools/pmc_to_json.py on the same bench command).  The record
+    names the sources it was measured on (kernel_sources_sha, commit); when the library this run loads was built from other
+    kernel sources the counters are NOT reported (the caller nulls them and sets counters_stale)."""
     try:
-        return json.load(open(COUNTERS_JSON)).get(workload, {})
+        u = json.load(open(COUNTERS_JSON)).get(workload, {})
     except Exception:
         return {}
+    from speech_amd.srchash import kernel_sources_sha
+    u = dict(u)
+    u["stale"] = bool(u) and u.get("kernel_sources_sha") != kernel_sources_sha()
+    return u
+
+
+def counter_fields(u):
+    live = bool(u) and not u.get("stale")
+    pick = lambda k: (u.get(k) if live else None)                       # noqa: E731
+    return {"traffic": pick("hbm_bytes_per_launch"), "valu_util": pick("valu_util"), "mfma_util": pick("mfma_util"),
+            "lds_bank_conflict_frac": pick("lds_bank_conflict_frac"), "counters_from": u.get("source"), "counters_commit": u.get("commit"),
+            "counters_kernel_sources_sha": u.get("kernel_sources_sha"), "counters_stale": bool(u.get("stale")) if u else None}
+
+
+def output_check(work, picks=3):
+    """What the timed region left in work.Y, checked: every feature finite, the reference's last-bin / last-cepstrum / Nyquist
+    quirk on every frame (c/kaldi_fbank.c:350, c/kaldi_mfcc.c:333, c/kaldi_spectrogram.c:244-248), and `picks` utterances (the
+    first, the shortest and the longest of the batch) against the CPU oracle on the same samples regenerated on the host, under
+    the parity rule of tests/compare.py.  The oracle is the checker here, never the thing timed."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import np_truth as T
+    import oracle_lib as O
+    from compare import check_parity, PARITY_LOG
+    D = int(work.plan.D)
+    Yv = work.Y.view(-1, D)
+    finite, quirk = True, True
+    for i in range(0, Yv.shape[0], 1 << 24):
+        blk = Yv[i:i + (1 << 24)]
+        finite = finite and bool(torch.isfinite(blk).all())
+        if D >= 2:
+            quirk = quirk and bool((blk[:, D - 1] == blk[:, D - 2]).all())
+    alias = {"snip": "snip", "win": "win"}
+    o = {alias.get(k, k): v for k, v in work.opts.items()}
+    truth = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}[work.kind]
+    tol = 1e-5 if work.kind == "spectrogram" else 1e-4
+    us = sorted({0, int(np.argmin(work.lens)), int(np.argmax(work.lens))})[:picks]
+    if float(o.get("dither", 0.0)) > 0.0:
+        us = []                                                        # dithered plans draw their own noise: no oracle to compare with
+    rows, ok = [], True
+    for u in us:
+        x = host_audio(work.ids[u:u + 1], work.lens[u:u + 1])[0].astype(np.float32)
+        W = int(work.batch.n_frames[u])
+        got = work.Y[int(work.batch.y_off[u]):int(work.batch.y_off[u]) + W * D].cpu().numpy().reshape(W, D)
+        _, ref = O.run(work.kind, x, single=True, **o)
+        _, ref_fast = O.run(work.kind, x, single=True, exact=False, **o)
+        good, e_go, e_gt, e_ot = check_parity(work.kind, o, got, ref, truth(x.astype(np.float64), single=True, **o), tol=tol, oracle_fast=ref_fast,
+                                              label="bench")
+        rows.append({"utt": int(work.ids[u]), "samples": int(work.lens[u]), "e_go": e_go, "hip_vs_f64": e_gt, "f32_cpu_vs_f64": e_ot,
+                     "rms_noise_ratio": PARITY_LOG[-1][6], "clause": PARITY_LOG[-1][2]})
+        ok = ok and good
+    return {"finite": finite, "last_bin_quirk": quirk, "tol": tol, "vs_oracle": rows, "ok": bool(finite and quirk and ok)}
+
+
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT a HIP call (the launcher parent must not initialise the GPU: it forks the ranks):
+    the *_VISIBLE_DEVICES lists if set, else the KFD topology nodes that have SIMDs.  None when neither can be read."""
+    counts = []
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            counts.append(len([t for t in v.split(",") if t.strip()]))
+    if counts:
+        return min(counts)
+    n, seen = 0, False
+    import glob
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(path):
+                if line.startswith("simd_count"):
+                    seen = True
+                    n += 1 if int(line.split()[1]) > 0 else 0
+        except OSError:
+            pass
+    return n if seen else None
 
 
 def spawn_ranks(n, argv):
     """--gpus N without a launcher: start N fresh ranks of this script (the parent makes no GPU call), wait for them."""
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1" or os.environ.get("BENCH_LAUNCH_TEST") == "1"
     if not rehearsal:
-        import torch
-        ndev = torch.cuda.device_count()                               # does not initialise the GPU
-        if ndev < n:
-            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (BENCH_REHEARSAL=1 runs every rank on GPU 0 with gloo)\n" % (n, ndev))
-            return 2
+        ndev = visible_gpu_count()                                     # sysfs / environment only: the parent makes no HIP call
+        if ndev is not None and ndev < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (BENCH_REHEARSAL=1 runs every rank on GPU 0)\n" % (n, ndev))
+            return 2                                                   # (ndev unknown: every rank checks its own device below)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -328,23 +416,24 @@ def main():
     # BENCH_LAUNCH_TEST=1 (tests/test_bench_launcher.py, CPU): the ranks form the gloo group and report, without any GPU work.
     launch_test = os.environ.get("BENCH_LAUNCH_TEST") == "1"
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1" or launch_test
+    if not rehearsal and local_rank >= torch.cuda.device_count():       # before the group forms: every rank of a node sees the same count
+        sys.stderr.write("bench.py: --gpus %d but rank %d has no GPU %d (%d visible)\n" % (args.gpus, rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     if world > 1:
-        if rehearsal:
-            # gloo's C++ side reports its connections on stdout ("[Gloo] Rank 0 is connected to ..."); stdout carries the ONE
-            # JSON line and nothing else, so file descriptor 1 points at stderr while the group forms
+        # ONE code path for rehearsals and real runs: the process group is gloo on CPU tensors.  It carries the barrier and the
+        # gather of a few numbers per rank -- the data path has no exchange step and RCCL is not linked.
+        # gloo's C++ side reports its connections on stdout ("[Gloo] Rank 0 is connected to ..."); stdout carries the ONE
+        # JSON line and nothing else, so file descriptor 1 points at stderr while the group forms
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
             sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group("gloo")
-                dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            os.dup2(saved, 1)
+            os.close(saved)
     if launch_test:
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if world > 1:
@@ -354,17 +443,17 @@ def main():
         if rank == 0:
             print(json.dumps({"launch_test": True, "n_gpus": world, "max_rank_plus_1": float(t.item())}))
         return
+    # the only difference between a rehearsal and a real run: which device the rank selects
     device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
-    cpu_group = rehearsal
+    props = torch.cuda.get_device_properties(device)
+    dev_info = {"name": props.name, "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+                "uuid": str(getattr(props, "uuid", "")), "hip_device": device.index, "pid": os.getpid()}
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            if cpu_group:
-                dist.barrier()
-            else:
-                dist.barrier(device_ids=[local_rank])
+            dist.barrier()
         torch.cuda.synchronize()
 
     nutt = args.nutt or WORKLOADS[args.workload]["nutt"]
@@ -387,12 +476,14 @@ def main():
     elapsed = time.perf_counter() - t0
     k_avg = ev0.elapsed_time(ev1) / args.steps
     mine = [elapsed, work.audio_s, k_avg, float(work.bytes)]
-    per = [mine]
+    per, infos = [mine], [dev_info]
     if world > 1:
-        t = torch.tensor(mine, device="cpu" if cpu_group else device, dtype=torch.float64)
+        t = torch.tensor(mine, dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)                                       # bookkeeping only: 4 doubles per rank
-        per = [[float(v) for v in a.cpu()] for a in allt]
+        dist.all_gather(allt, t)                                       # bookkeeping only: 4 doubles per rank, CPU tensors
+        per = [[float(v) for v in a] for a in allt]
+        infos = [None] * world
+        dist.all_gather_object(infos, dev_info)                        # which card each rank ran on
     elapsed = max(p[0] for p in per)                                   # MAX over ranks
     total_audio_s = sum(p[1] for p in per)
 
@@ -401,6 +492,11 @@ def main():
         k_iso, k_min = work.kernel_ms(stream)
         achieved = work.bytes / (k_avg * 1e-3) / 1e9
         u = utilisation(args.workload)
+        check = output_check(work)                                     # what the timed launches wrote, before anything overwrites it
+        # compute-side figure: SURVEY.md 8(d)'s algorithmic flop (sparse mel, real FFT as 2.5 n log2 n) against the f32 vector peak
+        o_ = work.opts
+        flop_frame = ALG_FLOP_PER_FRAME[work.kind] + (2.0 * o_.get("B", 23) * o_.get("C", 13) if work.kind == "mfcc" else 0.0)
+        tflops = flop_frame * float(work.batch.total_frames) / (k_avg * 1e-3) / 1e12
         out = {
             "metric": "audio-sec processed/sec (RTF^-1), 16 kHz", "value": total_audio_s * args.steps / elapsed, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -410,13 +506,18 @@ def main():
                        "feature_dim": int(work.plan.D), "tuned_kernel": bool(work.plan.tuned), "rehearsal_on_one_gpu": bool(rehearsal and world > 1),
                        "sharding": "utterances over ranks (LPT on sample counts), no collective on the data path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": u.get("hbm_bytes_per_launch"), "valu_util": u.get("valu_util"), "mfma_util": u.get("mfma_util"),
-                         "lds_bank_conflict_frac": u.get("lds_bank_conflict_frac"), "counters_from": u.get("source"),
+                         **counter_fields(u),
+                         "compute_side": {"algorithmic_flop_per_frame": flop_frame, "achieved_tflops": tflops, "peak_tflops_f32_valu": FP32_VALU_PEAK_TFLOPS,
+                                          "frac": tflops / FP32_VALU_PEAK_TFLOPS,
+                                          "nearer_bound": "valu" if tflops / FP32_VALU_PEAK_TFLOPS > achieved / HBM_PEAK_GBS else "hbm"},
                          "kernel_ms_avg": k_avg, "kernel_ms_isolated_avg": k_iso, "kernel_ms_isolated_min": k_min,
                          "algorithmic_bytes_per_launch": work.bytes},
+            "output_check": check,
             "per_gpu": [{"rank": r, "audio_s_per_s": p[1] * args.steps / p[0], "kernel_ms_avg": p[2], "audio_s": p[1],
-                         "roofline_frac_hbm": p[3] / (p[2] * 1e-3) / 1e9 / HBM_PEAK_GBS} for r, p in enumerate(per)],
+                         "roofline_frac_hbm": p[3] / (p[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "device": infos[r]} for r, p in enumerate(per)],
         }
+        if not check["ok"]:
+            sys.stderr.write("bench.py: the timed output FAILED its check: %s\n" % json.dumps(check))
         if not args.no_extras and world == 1:       # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(work)
             out["pcie_inclusive_audio_s_per_s"] = pcie_inclusive(work, device)
@@ -436,9 +537,11 @@ def main():
             kw = w.sustained_ms(args.steps)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.steps
-            uo = utilisation(name)
+            cf = counter_fields(utilisation(name))
+            oc = output_check(w, picks=1)
             others[name] = {"audio_s_per_s_per_gpu": w.audio_s / dt, "kernel_ms_avg": kw, "roofline_frac_hbm": w.bytes / (kw * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "valu_util": uo.get("valu_util"), "mfma_util": uo.get("mfma_util"), "tuned_kernel": bool(w.plan.tuned)}
+                            "valu_util": cf["valu_util"], "mfma_util": cf["mfma_util"], "counters_stale": cf["counters_stale"], "tuned_kernel": bool(w.plan.tuned),
+                            "output_ok": oc["ok"], "e_go": oc["vs_oracle"][0]["e_go"] if oc["vs_oracle"] else None}
             w.free()
             torch.cuda.empty_cache()
         out["other_workloads_1gpu"] = others
@@ -449,6 +552,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        if not out["output_check"]["ok"]:
+            sys.exit(3)                                                # a bench line whose output failed its check is not a result
 
 
 if __name__ == "__main__":

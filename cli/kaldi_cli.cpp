@@ -154,7 +154,7 @@ static void put_ark_header(ostream &os, const string &key, bool f64, size_t W, s
 
 // --wav_scp: every line's .wav through the plan, in groups of at most `group_samples` samples, into one archive
 static int run_wav_scp(const string &list, const speech_opts &o_in, bool have_r, unsigned channel, ostream &os, long long ark_off, const string &ofile,
-                       const string &scp_file, size_t group_samples)
+                       const string &scp_file, size_t group_samples, const vector<int> &devices)
 {
     ifstream ls(list);
     if (!ls) { FAIL("problem opening the wav_scp file"); }
@@ -198,7 +198,7 @@ static int run_wav_scp(const string &list, const speech_opts &o_in, bool have_r,
                 o.sr = (double)it.wav.rate;
                 if (o.kind != SPEECH_SPECTROGRAM && o_in.hif < DBL_EPSILON) { o.hif = 0.5 * o.sr + o_in.hif; }
                 if (o.kind != SPEECH_SPECTROGRAM && o.hif <= o.lof) { FAIL("hif must be > lof"); }
-                if (speech_plan_create(&plan, &o, 0)) { FAIL("problem during function call"); }
+                if (speech_plan_create(&plan, &o, devices.empty() ? 0 : devices[0])) { FAIL("problem during function call"); }
                 speech_plan_sizes(plan, nullptr, nullptr, nullptr, &D, nullptr);
             }
             else if ((double)it.wav.rate != o.sr) { speech_plan_destroy(plan); FAIL("sample rate differs from the first file's: " + en.second); }
@@ -215,7 +215,11 @@ static int run_wav_scp(const string &list, const speech_opts &o_in, bool have_r,
             ys[i].resize(ww[i] * D + 1);
             xp[i] = items[i].wav.x.data(); yp[i] = ys[i].data(); ids[i] = (unsigned)(done + i);
         }
-        if (speech_plan_run_host(plan, n, xp.data(), nn.data(), yp.data(), 1, 0, ids.data())) { speech_plan_destroy(plan); FAIL("problem during function call"); }
+        // --devices: the group is dealt over the listed GPUs inside the library (speech_run_host_multi: a thread, a plan and a
+        // staging pipeline per device, no collective); the archive is the same to the bit, dither included
+        const int rc = (devices.size() > 1) ? speech_run_host_multi(&o, (int)devices.size(), devices.data(), n, xp.data(), nn.data(), yp.data(), 1, 0, ids.data())
+                                            : speech_plan_run_host(plan, n, xp.data(), nn.data(), yp.data(), 1, 0, ids.data());
+        if (rc) { speech_plan_destroy(plan); FAIL("problem during function call"); }
         for (size_t i = 0; i < n; ++i)
         {
             put_ark_header(os, items[i].key, false, ww[i], D);
@@ -287,6 +291,7 @@ static void usage()
     printf(fmt, "--channel=<n>", "with a .wav input: the channel to use [default=0]");
     printf(fmt, "--raw=<f32|f64|s16>", "the input is headerless samples of this type; the output is headerless too");
     printf(fmt, "--wav_scp=<file>", "list of \"<utt-id> <.wav path>\" lines instead of <file>; -o is a Kaldi archive");
+    printf(fmt, "--devices=<a,b,..>", "with --wav_scp: the GPUs to share the list (one pipeline each) [default: 0]");
     printf(fmt, "--seed=<n>", "dither seed [default: from the clock, as the reference: a new noise draw on every run]");
     printf(fmt, "--utt=<n>", "with --seed: the utterance number the dither generator is keyed on [default: a per-process call counter]");
     printf(fmt, "-h, --help", "display this help and exit");
@@ -307,6 +312,7 @@ int main(int argc, char *argv[])
     bool have_seed = false;
     int snipe = 0, dc0 = 0, rawe = 0, amp = 0, lg = 0, usee = 0, mn0 = 0, help = 0;
     string wintype = "povey", ofile, ark_key, scp_file, wav_scp, raw_type;
+    vector<int> devices;
     bool have_o = false, append = false, have_r = false;
 
     static const option longopts[] = {
@@ -317,7 +323,7 @@ int main(int argc, char *argv[])
         {"B", required_argument, nullptr, 'b'}, {"log", no_argument, nullptr, 'g'}, {"C", required_argument, nullptr, 'c'}, {"Q", required_argument, nullptr, 'q'},
         {"use_energy", no_argument, nullptr, 'x'}, {"zero_mean", no_argument, nullptr, 'm'}, {"ofile", required_argument, nullptr, 'o'},
         {"help", no_argument, nullptr, 'h'}, {"compress", required_argument, nullptr, 1000}, {"cep_scale", required_argument, nullptr, 1001},
-        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {"wav_scp", required_argument, nullptr, 1006}, {"raw", required_argument, nullptr, 1007}, {"seed", required_argument, nullptr, 1008}, {"utt", required_argument, nullptr, 1009}, {nullptr, 0, nullptr, 0}};
+        {"ark", required_argument, nullptr, 1002}, {"scp", required_argument, nullptr, 1003}, {"append", no_argument, nullptr, 1004}, {"channel", required_argument, nullptr, 1005}, {"wav_scp", required_argument, nullptr, 1006}, {"raw", required_argument, nullptr, 1007}, {"seed", required_argument, nullptr, 1008}, {"utt", required_argument, nullptr, 1009}, {"devices", required_argument, nullptr, 1010}, {nullptr, 0, nullptr, 0}};
     const char *shortopts = TOOL == TOOL_SPECTROGRAM ? "r:t:s:ed:zyp:w:mo:h" : TOOL == TOOL_FBANK ? "r:t:s:ed:zyp:w:al:u:b:gxmo:h" : "r:t:s:ed:zyp:w:l:u:b:c:q:xmo:h";
     int c, nerrs = 0;
     opterr = 0;
@@ -344,6 +350,13 @@ int main(int argc, char *argv[])
             case 1007: raw_type = optarg; if (raw_type != "f32" && raw_type != "f64" && raw_type != "s16") { ++nerrs; } break;
             case 1008: seed = strtoull(optarg, &end, 0); have_seed = true; if (end == optarg || *end) { ++nerrs; } break;
             case 1009: utt = strtol(optarg, &end, 10); if (end == optarg || *end || utt < 0) { ++nerrs; } break;
+            case 1010:
+            {
+                const char *q = optarg;
+                while (*q) { const long v = strtol(q, &end, 10); if (end == q || v < 0 || v > 1023) { ++nerrs; break; } devices.push_back((int)v); q = (*end == ',') ? end + 1 : end; if (*end && *end != ',') { ++nerrs; break; } }
+                if (devices.empty()) { ++nerrs; }
+                break;
+            }
             case 1005: channel = strtol(optarg, &end, 10); if (end == optarg || *end || channel < 0) { ++nerrs; } break;
             default: ++nerrs; cerr << prog() << ": invalid option \"" << argv[optind - 1] << "\"" << endl; break;
         }
@@ -355,6 +368,7 @@ int main(int argc, char *argv[])
 
     const bool list_mode = !wav_scp.empty();
     if (list_mode && !ifile.empty()) { FAIL("--wav_scp replaces the input file"); }
+    if (!devices.empty() && !list_mode) { FAIL("--devices goes with --wav_scp"); }
     // stdin / stdout detection: src/kaldi_mfcc.cpp:151-159
     const bool stdi1 = !list_mode && (ifile.empty() || ifile == "-");
     if (stdi1 && isatty(fileno(stdin))) { FAIL("no stdin detected"); }
@@ -449,7 +463,7 @@ int main(int argc, char *argv[])
         speech_opts o; make_opts(o);
         timespec tic, toc;
         clock_gettime(CLOCK_REALTIME, &tic);
-        if (run_wav_scp(wav_scp, o, have_r, (unsigned)channel, ofs, off, ofile, scp_file, (size_t)64 << 20)) { return 1; }
+        if (run_wav_scp(wav_scp, o, have_r, (unsigned)channel, ofs, off, ofile, scp_file, ((size_t)64 << 20) * (devices.empty() ? 1u : devices.size()), devices)) { return 1; }
         clock_gettime(CLOCK_REALTIME, &toc);
         if (TOOL != TOOL_SPECTROGRAM) { cerr << "elapsed time = " << double(toc.tv_sec - tic.tv_sec) * 1e3 + double(toc.tv_nsec - tic.tv_nsec) / 1e6 << " ms" << endl; }
         return 0;

@@ -110,6 +110,26 @@ int speech_plan_run_host(speech_plan *plan, size_t nutt, const void *const *X, c
                          int pcm16, size_t chunk_bytes, const unsigned int *ids);
 void speech_host_release(void);
 
+/* The same from ONE call over several GPUs of a node: what a C caller of the reference (src/kaldi_mfcc.cpp:283-308, one call
+   per utterance on one thread) needs to use all of them.  devices[0 .. ndev-1] are HIP device numbers (a number may repeat:
+   two pipelines on one device).  The utterances are dealt to the devices by speech_shard_utterances (longest first to the
+   least loaded device); every device gets its own host thread, its own plan (tables on that device) and its
+   own two-stream pinned staging pipeline, exactly speech_plan_run_host's; there is no collective and no peer copy.  Utterance
+   u draws its dither as utterance number ids[u] (NULL: u), so the features equal the single-device run bit for bit whatever
+   ndev is.  Synchronous.  The option set and every utterance's length are validated before any device is touched (messages
+   as the drop-in functions').  A device that fails (cannot be selected, an allocation or any HIP call fails) does not fail
+   the call while another device works: its utterances are dealt again, once, to the devices that finished their share, with
+   a line on stderr; the call returns 1 only if every device failed or the second deal fails too. */
+int speech_run_host_multi(const speech_opts *opts, int ndev, const int *devices, size_t nutt, const void *const *X,
+                          const size_t *n_samples, void *const *Y, int pcm16, size_t chunk_bytes, const unsigned int *ids);
+/* The assignment alone (host arithmetic, no device): shard[u] in [0, nshards) for every utterance; longest-processing-time
+   greedy on the sample counts, ties to the lower index / lower shard.  Identical to speech_amd.api.shard_utterances. */
+int speech_shard_utterances(size_t nutt, const size_t *n_samples, int nshards, int *shard);
+/* Validation and sizes without a plan or a device: checks opts as the reference prologue does (c/kaldi_mfcc.c:54-78) and N as
+   c/kaldi_mfcc.c:70-77, and returns the frame count W of an utterance of N samples and the feature dimension D (either
+   pointer may be NULL) -- what a caller needs to size Y, as src/kaldi_mfcc.cpp:255-261 computes it by hand. */
+int speech_opts_frames(const speech_opts *opts, size_t N, size_t *W, size_t *D);
+
 /* Widening: corpus post-processing on a batch's packed features Y_dev (frame-major W x D per utterance,
    the layout speech_batch_run writes).  The reference's only post-pass is mn0, the per-utterance mean subtraction
    (c/kaldi_fbank.c:355-370, c/kaldi_mfcc.c:337-352); these generalise it to Kaldi's apply-cmvn, add-deltas and

@@ -24,7 +24,7 @@ EXT_SYMBOLS = [
     "speech_batch_run", "speech_batch_run_timed", "speech_batch_run_pcm16",
     "speech_batch_stats", "speech_batch_cmvn", "speech_batch_affine", "speech_batch_add_deltas", "speech_batch_splice",
     "speech_batch_splice_subsample", "speech_batch_subsample_rows", "speech_extract_pcm16", "speech_batch_set_ids", "speech_plan_run_host", "speech_host_release",
-    "speech_batch_cmvn_noalloc", "speech_set_dropin_dither", "speech_batch_synth_audio", "speech_synth_audio_host",
+    "speech_batch_cmvn_noalloc", "speech_run_host_multi", "speech_shard_utterances", "speech_opts_frames", "speech_set_dropin_dither", "speech_batch_synth_audio", "speech_synth_audio_host",
 ]
 
 
@@ -104,6 +104,9 @@ def load():
     lib.speech_batch_set_ids.argtypes = [vp, C.POINTER(C.c_uint)]; lib.speech_batch_set_ids.restype = i
     lib.speech_plan_run_host.argtypes = [vp, z, C.POINTER(vp), C.POINTER(z), C.POINTER(vp), i, z, C.POINTER(C.c_uint)]; lib.speech_plan_run_host.restype = i
     lib.speech_host_release.argtypes = []; lib.speech_host_release.restype = None
+    lib.speech_run_host_multi.argtypes = [po, i, C.POINTER(i), z, C.POINTER(vp), C.POINTER(z), C.POINTER(vp), i, z, C.POINTER(C.c_uint)]; lib.speech_run_host_multi.restype = i
+    lib.speech_shard_utterances.argtypes = [z, C.POINTER(z), i, C.POINTER(i)]; lib.speech_shard_utterances.restype = i
+    lib.speech_opts_frames.argtypes = [po, z, pz, pz]; lib.speech_opts_frames.restype = i
     lib.speech_extract_pcm16.argtypes = [C.POINTER(SpeechOpts), C.POINTER(C.c_short), z, vp]; lib.speech_extract_pcm16.restype = i
     _lib = lib
     return lib

@@ -122,6 +122,59 @@ def extract_pcm16(kind, X16, dtype="f32", **kw):
     return Y[:W]
 
 
+def opts_frames(kind, N, dtype="f32", **kw):
+    """(W, D) of an utterance of N samples under these options: speech_opts_frames -- validation and sizes in the library's
+    own arithmetic, no plan, no device.  Raises SpeechError where the reference's prologue would return 1."""
+    lib = _lib.load()
+    o = make_opts(kind, dtype, **kw)
+    W, D = C.c_size_t(), C.c_size_t()
+    if lib.speech_opts_frames(C.byref(o), int(N), C.byref(W), C.byref(D)) != 0:
+        raise SpeechError(_lib.last_error())
+    return W.value, D.value
+
+
+def shard_assignment(n_samples, nshards):
+    """speech_shard_utterances: the library's own (C) statement of shard_utterances below, as one shard number per
+    utterance.  Host arithmetic only."""
+    lib = _lib.load()
+    n = np.ascontiguousarray(n_samples, dtype=np.uint64)
+    out = np.zeros(max(1, n.size), dtype=np.int32)
+    if lib.speech_shard_utterances(n.size, n.ctypes.data_as(C.POINTER(C.c_size_t)), int(nshards), out.ctypes.data_as(C.POINTER(C.c_int))) != 0:
+        raise SpeechError(_lib.last_error())
+    return out[:n.size]
+
+
+def run_host_multi(kind, xs, devices, dtype="f32", chunk_bytes=0, ids=None, **kw):
+    """speech_run_host_multi: a list of utterances in host memory (numpy arrays of `dtype`, or all int16) over the HIP
+    devices `devices` from ONE call -- a host thread, a plan and a two-stream staging pipeline per device inside the library,
+    LPT sharding, no collective.  Returns the list of W_u x D arrays; equal bit for bit to Plan.run_host on one device."""
+    lib = _lib.load()
+    o = make_opts(kind, dtype, **kw)
+    t = np.float64 if o.dtype == _lib.F64 else np.float32
+    n = len(xs)
+    pcm16 = n > 0 and all(np.asarray(x).dtype == np.int16 for x in xs)
+    xs = [np.ascontiguousarray(x, dtype=np.int16 if pcm16 else t).reshape(-1) for x in xs]
+    ys = []
+    W, D = C.c_size_t(), C.c_size_t()
+    for x in xs:
+        if lib.speech_opts_frames(C.byref(o), x.size, C.byref(W), C.byref(D)) != 0:
+            raise SpeechError(_lib.last_error())
+        ys.append(np.zeros((W.value, D.value), dtype=t))
+    dev = (C.c_int * max(1, len(devices)))(*[int(d) for d in devices])
+    Xp = (C.c_void_p * max(1, n))(*[x.ctypes.data for x in xs])
+    Yp = (C.c_void_p * max(1, n))(*[y.ctypes.data if y.size else xs[0].ctypes.data for y in ys])
+    Np = (C.c_size_t * max(1, n))(*[x.size for x in xs])
+    idp = None
+    if ids is not None:
+        ida = np.ascontiguousarray(ids, dtype=np.uint32)
+        if ida.shape != (n,):
+            raise ValueError("ids must have one entry per utterance")
+        idp = ida.ctypes.data_as(C.POINTER(C.c_uint))
+    if lib.speech_run_host_multi(C.byref(o), len(devices), dev, n, Xp, Np, Yp, int(pcm16), int(chunk_bytes), idp) != 0:
+        raise SpeechError(_lib.last_error())
+    return ys
+
+
 class Plan:
     """speech_plan: the per-call tables of c/kaldi_mfcc.c:105-210, built once on one device."""
 

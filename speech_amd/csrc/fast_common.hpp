@@ -96,7 +96,9 @@ struct FastParams {
     int do_dither;                      // c/kaldi_mfcc.c:243: dither > FLT_EPSILON
     float dither;
     unsigned long long seed;
-    int ablate;                         // diagnostics only (SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads, 4 = mel kinds stop after the FFT, 8 = stores land in a 2 MB (L2-resident) window, 16 = every utterance reads utterance 0's audio, 32 / 64 = mel kinds stop after the power tile / after the mel contraction, 256 = mel kinds load their audio through registers (no buffer_load ... lds)
+#ifdef SPEECH_DIAG
+    int ablate;                         // libspeech_diag.so only (make diag; SPEECH_ABLATE): 1 = no feature stores, 2 = no audio loads, 4 = mel kinds stop after the FFT, 8 = stores land in a 2 MB (L2-resident) window, 16 = every utterance reads utterance 0's audio, 32 / 64 = mel kinds stop after the power tile / after the mel contraction, 256 = mel kinds load their audio through registers (no buffer_load ... lds)
+#endif
     const float *tab;
     // mel kinds
     const float *melw, *mat2, *aux;
@@ -106,6 +108,14 @@ struct FastParams {
     float compress;
     int mel_kbeg[MAX_MTILES], mel_ksteps[MAX_MTILES], mel_woff[MAX_MTILES], mel_first[MAX_MTILES], mel_cnt[MAX_MTILES];
 };
+
+// Timing diagnostics exist only in libspeech_diag.so (`make diag`, -DSPEECH_DIAG): the release library has no
+// such field, reads no environment variable on the launch path and its kernels carry none of the switches.
+#ifdef SPEECH_DIAG
+#define SPEECH_ABL(p) ((p).ablate)
+#else
+#define SPEECH_ABL(p) 0
+#endif
 
 typedef void (*kernel_fn)(const FastParams);
 // the instantiation that serves a plan: nz = rows of samples that hold data (9..16), pair = two frames per transform
@@ -274,6 +284,25 @@ __device__ __forceinline__ float fast_rcp(float x)
 }
 
 __device__ __forceinline__ float floor_log(float v) { return pos_log(fmaxf(v, FLT_EPSILON)); }
+
+// x^c for x >= 0, 0 < c <= 1 (plp's spectral compression, powf in the reference: c/kaldi_plp.c:355).  exp2(c log2 x) on the
+// whole value carries v_log_f32's 1 ulp of log2 x ~ 2e-6 at x ~ 1e9 into the exponent: 4-5 ulp on the result, which
+// Levinson-Durbin then amplifies (round 2: HIP 2 x the CPU arithmetic's noise on short plp cases).  Split instead: x = m 2^e,
+// log2 m from the hardware on [0.5, 1) (abs error ~1e-7), c e as an exact two-term product (hi + lo by fma), the integer part
+// of the exponent applied by ldexp: ~1.5 ulp for 8 more instructions per mel value.
+__device__ __forceinline__ float pow_split(float x, float c)
+{
+    const float m = __builtin_amdgcn_frexp_mantf(x);
+    const float e = (float)__builtin_amdgcn_frexp_expf(x);
+    const float hi = c * e;
+    const float lo = fmaf(c, e, -hi);
+    const float ti = __builtin_rintf(hi);
+    const float r = (hi - ti) + fmaf(c, __log2f(m), lo);
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(r), (int)ti);
+}
+#ifndef PLP_IEEE_DIV
+#define PLP_IEEE_DIV 1
+#endif
 
 // spectrogram: log(max(q / 4, FLT_EPSILON)) for q = 4 |X|^2, exponent and mantissa split as in pos_log: v_log_f32 on the
 // whole value is 1 ulp of log2(q) ~ 2e-6 at q ~ 1e9, which measured as 1.2-1.4 x the float32 CPU arithmetic's rms distance
@@ -1108,7 +1137,7 @@ struct Prefetch {
 template <bool PCM, int NP = NPRE>
 __device__ __forceinline__ void prefetch_issue(Prefetch<NP> &pf, const FastParams &p, const float *xu, const short *xu16, long long s0, int need, long long N, int nfr, int lane)
 {
-    pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NP) && !(p.ablate & 2);
+    pf.on = (nfr > 0) && (s0 >= 0) && (s0 + need <= N) && (need <= 64 * NP) && !(SPEECH_ABL(p) & 2);
     if (PCM)
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xu16 + (pf.on ? s0 : 0)), 0, pf.on ? need * 2 : 0, BUF_FLAGS);

@@ -78,9 +78,12 @@ bool fast_supported(const speech_opts &o, size_t L, size_t nfft) { return fast_g
 
 int fast_tile_frames(const speech_opts &o, size_t L, size_t nfft) { return fast_geom(o, L, nfft).tile; }
 
-// Opt a kernel in to 64 KB of dynamic LDS (100 KB for the 2048-point kernels; fast_geom admits nothing larger), once per device.  Done when the plan is
-// created, so that speech_batch_run itself only launches (and can be captured in a HIP graph).
-static hipError_t opt_in_lds(kernel_fn k, int bytes)
+// Opt a kernel in to `bytes` of dynamic LDS, once per (device, kernel).  The attribute belongs to the kernel on a device, not to
+// a plan, so every caller asks for the LARGEST size its host layer admits for that kernel (64 KB / 100 KB for the tuned kernels,
+// 160 KB for the generic frame kernels, 2 x 4097 doubles for the affine pass): whichever plan is created first, every later
+// plan's launch fits.  Done when a plan is created, so that speech_batch_run itself only launches (and can be captured in a
+// HIP graph).
+hipError_t opt_in_lds_once(const void *k, int bytes)
 {
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> opted;
@@ -88,14 +91,16 @@ static hipError_t opt_in_lds(kernel_fn k, int bytes)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) { return e; }
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_pair(dev, reinterpret_cast<const void *>(k));
+    const auto key = std::make_pair(dev, k);
     if (opted.insert(key).second)
     {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { opted.erase(key); }
     }
     return e;
 }
+
+static hipError_t opt_in_lds(kernel_fn k, int bytes) { return opt_in_lds_once(reinterpret_cast<const void *>(k), bytes); }
 
 static kernel_fn plan_kernel(const FastTables *t, bool dither, bool pcm)
 {
@@ -260,7 +265,9 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, hipStr
     p.snip_edges = fp.snip_edges; p.dc0 = fp.dc0; p.want_pre = fp.want_pre; p.want_post = fp.want_post;
     p.preemph = fp.do_preemph ? fp.preemph : 0.0f;
     p.do_dither = fp.do_dither; p.dither = fp.dither; p.seed = fp.seed;
-    { const char *ab = getenv("SPEECH_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }     // timing diagnostics, DESIGN.md 4.3
+#ifdef SPEECH_DIAG
+    { const char *ab = getenv("SPEECH_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }     // libspeech_diag.so only: timing diagnostics, DESIGN.md 4.3
+#endif
     p.tab = t->d_tab;
     p.melw = t->d_melw; p.mat2 = t->d_mat2; p.aux = t->d_aux;
     p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;

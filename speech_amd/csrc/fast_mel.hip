@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     {
         const long long w0 = (long long)tile.frame0 + fbase + fq;
         const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
-        if (!(p.ablate & 2)) load_span<XW>(s_aud, p.X + ((p.ablate & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane, (p.ablate & 256) ? 0 : (p.ws & ~255));
+        if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (p.ws & ~255));
     }
     __syncthreads();
 
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     // The power tile takes the slices' place.  When a slice is exactly as long as the wave's rows of the tile (the usual
     // case: ws = FWK * PPK), a wave's rows lie in its own slice and it only has to be done with its own transposition image.
     if (p.ws != FWK * PPK) { __syncthreads(); } else { wave_sync(); }
-    if (p.ablate & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
+    if (SPEECH_ABL(p) & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILEK x 257 tile, column 257 zero
     if (XW)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fbase + fq + f] = rawe; }       // column 257: the zero a padded k-loop may touch
     }
     __syncthreads();
-    if (p.ablate & 32) { if (s_pow[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
+    if (SPEECH_ABL(p) & 32) { if (s_pow[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
 
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
     const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
                 if (live)
                 {
                     const float x = v * p.aux[m];
-                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : __builtin_amdgcn_exp2f(p.compress * __log2f(x)));
+                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : pow_split(x, p.compress));
                     s_mel[fr * p.MP + 1 + m] = c;
                     if (m == 0) { s_mel[fr * p.MP] = c; }
                     if (m == p.B - 1) { for (int j = p.B + 1; j < p.K2; ++j) { s_mel[fr * p.MP + j] = (j == p.B + 1) ? c : 0.0f; } }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * p.D] = p.lg ? s_e[tid] : pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299 (its log, too, on the way out when lg)
     if (KIND == SPEECH_MFCC && tid < 4 * TILEK) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
     __syncthreads();
-    if (p.ablate & 64) { if (s_mel[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
+    if (SPEECH_ABL(p) & 64) { if (s_mel[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
 
     if (KIND == SPEECH_MFCC)
     {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
                 float ki = r[i + 1];
 #pragma unroll
                 for (int j = 0; j < i; ++j) { ki += a[j] * r[i - j]; }
-                ki *= fast_rcp(E);
+                ki = PLP_IEEE_DIV ? ki / E : ki * fast_rcp(E);              // the oracle's (and Kaldi's) k /= E
                 float c = 1.0f - ki * ki;
                 c = (c < 1.0e-5f) ? 1.0e-5f : c;
                 E *= c;

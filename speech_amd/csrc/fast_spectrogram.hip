@@ -26,7 +26,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
-    const float *xu = p.X + ((p.ablate & 16) ? 0 : utt.x_off);
+    const float *xu = p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off);
     const short *xu16 = p.X16 ? p.X16 + utt.x_off : nullptr;
     const long long N = (long long)utt.n;
     constexpr int FW = XW ? 1 : (WIDE ? 2 : (PAIR ? 2 * QF : QF));          // frames per wave
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
         // BEFORE this quad's stores are issued.  The loads were issued ahead of the whole FFT, and vmcnt retires in order,
         // so waiting for them here waits for nothing younger; the stores then drain behind the next quad's arithmetic.
         wave_sync();
-        prefetch_park<PCM, NPK, XW>(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, p.ablate);
+        prefetch_park<PCM, NPK, XW>(pf, s_aud, xu, xu16, s0n, needn, N, nfrn, lane, SPEECH_ABL(p));
         wave_sync();
         if (nfr > 0)
         {
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(NT, 4) void fast_spectrogram_kernel(const FastParam
             wave_sync();
             const float *so = s_aud + p.span;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(p.Y + ((p.ablate & 8) ? (unsigned long long)((blockIdx.x & 31u) * TILE_SPEC + (fq & (TILE_SPEC - 1))) * D      /* diagnostics */
-                                               : utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * D)), 0, (p.ablate & 1) ? 0 : nfr * D * 4, BUF_FLAGS);
+                (void *)(p.Y + ((SPEECH_ABL(p) & 8) ? (unsigned long long)((blockIdx.x & 31u) * TILE_SPEC + (fq & (TILE_SPEC - 1))) * D      /* diagnostics */
+                                               : utt.y_off + (unsigned long long)((long long)tile.frame0 + fq) * D)), 0, (SPEECH_ABL(p) & 1) ? 0 : nfr * D * 4, BUF_FLAGS);
             if (nfr == FW)
             {
                 // FW * D floats = FW D / 4 chunks of 16 bytes (4 x 257: four full instructions and one lane; 8 x 129: 258 chunks)

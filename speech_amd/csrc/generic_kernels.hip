@@ -401,7 +401,10 @@ hipError_t prepare_generic(int nfft, size_t lds)
 {
     // the instantiation launch_generic will pick, on the current device
     const void *k = (nfft <= 1024) ? reinterpret_cast<const void *>(&generic_frames_kernel<T, 64>) : reinterpret_cast<const void *>(&generic_frames_kernel<T, NT>);
-    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the attribute is the kernel's, not the plan's: opted in once per device to the largest size the host layer admits, so
+    // that a later, smaller plan cannot lower what an earlier, larger plan launches with
+    (void)lds;
+    return opt_in_lds_once(k, (int)GENERIC_MAX_LDS);
 }
 
 }  // namespace

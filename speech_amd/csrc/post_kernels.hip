@@ -263,7 +263,9 @@ hipError_t post_prepare(bool f64, int D)
     const size_t lds = (size_t)2 * (size_t)D * (f64 ? 8u : 4u);
     if (lds <= 48u * 1024u) { return hipSuccess; }
     const void *k = f64 ? reinterpret_cast<const void *>(&utt_affine_kernel<double>) : reinterpret_cast<const void *>(&utt_affine_kernel<float>);
-    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // once per (device, kernel), to the widest feature row the host layer admits (the spectrogram of an 8192-point frame:
+    // 4097 columns; fbank with energy: 4097): the attribute is the kernel's, not the plan's
+    return opt_in_lds_once(k, (int)(2u * ((size_t)GENERIC_MAX_NFFT / 2u + 1u) * 8u));
 }
 
 hipError_t launch_post(int what, bool f64, const PostParams &p, uint32_t max_frames, hipStream_t s)

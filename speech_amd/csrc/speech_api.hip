@@ -520,7 +520,7 @@ int speech_plan_create(speech_plan **out, const speech_opts *opts, int device)
     if (!p->tuned)
     {
         const size_t lds = generic_lds_bytes((int)sz.nfft, (int)o.B, (int)o.C, (int)p->P, o.dtype == SPEECH_F64 ? 8 : 4);
-        if (lds > 160u * 1024u) { speech_plan_destroy(p); return fail(fn, "frame of %zu samples does not fit in LDS (%zu bytes needed)", sz.L, lds); }
+        if (lds > GENERIC_MAX_LDS) { speech_plan_destroy(p); return fail(fn, "frame of %zu samples does not fit in LDS (%zu bytes needed)", sz.L, lds); }
         const hipError_t e = generic_prepare((int)sz.nfft, o.dtype == SPEECH_F64 ? 8u : 4u, lds);
         if (e != hipSuccess) { speech_plan_destroy(p); return fail(fn, "cannot reserve %zu bytes of LDS for the frame kernel: %s", lds, hipGetErrorString(e)); }
     }
@@ -557,6 +557,25 @@ int speech_plan_num_frames(const speech_plan *p, size_t N, size_t *W)
     if (p->o.snip_edges && p->sz.L > N) { return 1; }                  // c/kaldi_mfcc.c:70
     const size_t w = p->o.snip_edges ? 1u + (N - p->sz.L) / p->sz.stp : (N + p->sz.stp / 2u) / p->sz.stp;   // c/kaldi_mfcc.c:77
     if (W) { *W = w; }
+    return 0;
+}
+
+int speech_opts_frames(const speech_opts *opts, size_t N, size_t *W, size_t *D)
+{
+    const char *fn = "speech_opts_frames";
+    if (W) { *W = 0; }
+    if (!opts) { return fail(fn, "null options"); }
+    speech_opts o = *opts;
+    o.win_type[sizeof(o.win_type) - 1] = '\0';
+    Sizes sz;
+    if (o.dtype == SPEECH_F64 ? validate<double>(o, &sz) : validate<float>(o, &sz)) { return 1; }
+    const char *kfn = kind_name(o.kind, o.dtype);
+    if (!window_known(o.win_type)) { return fail(kfn, "window type must be rectangular, blackman, hamming, hann or povey (lower-cased)"); }
+    if (D) { *D = sz.D; }
+    if (N < 1u) { return fail(kfn, "N (nsamps in signal) must be positive"); }
+    if (N > 2147483647u) { return fail(kfn, "%zu samples not supported (int-indexed)", N); }              // c/kaldi_mfcc.c:82-84
+    if (o.snip_edges && sz.L > N) { return fail(kfn, "frame length must be < signal length if snip_edges"); }   // c/kaldi_mfcc.c:70
+    if (W) { *W = o.snip_edges ? 1u + (N - sz.L) / sz.stp : (N + sz.stp / 2u) / sz.stp; }                 // c/kaldi_mfcc.c:77
     return 0;
 }
 

@@ -193,6 +193,8 @@ hipError_t launch_generic_f32(const FrameParams<float> &p, hipStream_t s);
 hipError_t launch_generic_f64(const FrameParams<double> &p, hipStream_t s);
 size_t generic_lds_bytes(int nfft, int B, int C, int P, size_t elem);
 hipError_t generic_prepare(int nfft, size_t elem, size_t lds);
+constexpr size_t GENERIC_MAX_LDS = (size_t)160 * 1024;                      // what speech_plan_create admits for a generic plan: a CU's LDS
+hipError_t opt_in_lds_once(const void *kernel, int bytes);                  // fast_kernels.hip: once per (device, kernel), always to the kernel's largest admitted size
 hipError_t post_prepare(bool f64, int D);                                  // the affine pass keeps 2 D scale / offset values in LDS
 
 constexpr int GENERIC_TILE_FRAMES = 8;

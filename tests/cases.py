@@ -60,7 +60,8 @@ _add("fbank", 2000, 514, B=1, use_energy=1)
 _add("fbank", 2000, 515, B=2, lof=0.0, hif=8000.0)
 _add("fbank", 2000, 516, B=23, lof=0.0, hif=9000.0)              # hif above Nyquist is not rejected: c/kaldi_mfcc.c:61
 _add("plp", 2000, 520, compress=1.0)
-_add("plp", 16000, 521, compress=0.5, Q=0.0, cep_scale=2.0)     # 98 frames: the rms noise ratio of 10 frames of an order-12 recursion scatters by +-50 %
+_add("plp", 2000, 521, compress=0.5, Q=0.0, cep_scale=2.0)      # 10 frames (round 2 lengthened this case after HIP measured 2 x the CPU arithmetic's noise on it; restored in round 3, the cause -- exp2(c log2 x) for powf -- fixed in fast_common.hpp pow_split)
+_add("plp", 16000, 521, compress=0.5, Q=0.0, cep_scale=2.0)     # the same options over 98 frames
 _add("plp", 2000, 522, B=15, C=8)
 _add("plp", 2000, 523, B=23, C=13, order=16)
 
@@ -94,7 +95,8 @@ for j, (sr, snip, dc0, rawe) in enumerate(((44100.0, 1, 1, 1), (48000.0, 0, 0, 0
          win=("povey", "hamming", "hann", "blackman")[j], preemph=(0.97, 0.0, 0.5, 0.97)[j])
 _add("mfcc", 2048, 940, sr=16000.0, fl=128.0, fs=32.0)           # L=2048 == nfft, one frame
 _add("fbank", 9000, 941, sr=16000.0, fl=64.0625, fs=10.0, B=23)   # L=1025: the shortest 2048-point frame
-_add("spectrogram", 9000, 944, sr=16000.0, fl=100.0, fs=12.5, snip=0)   # L=1600, stp=200 (seed 942: passes the rms clause at 0.97, its largest deviation is 2.1 x the CPU arithmetic's against the 2 x allowed)
+_add("spectrogram", 9000, 942, sr=16000.0, fl=100.0, fs=12.5, snip=0)   # L=1600, stp=200.  Seed 942 is the case round 2 re-drew (rms noise ratio 0.97, largest deviation 2.1 x the CPU arithmetic's); it is back, with compare.MAX_MARGIN stating the measured spread instead
+_add("spectrogram", 9000, 944, sr=16000.0, fl=100.0, fs=12.5, snip=0)   # the seed round 2 moved it to
 _add("plp", 40000, 943, sr=48000.0, hif=24000.0, fs=40.0, snip=0)       # stp=1920 > L=1200: gaps between frames
 _add("fbank", 3000, 651, sr=16000.0, fl=32.0625, fs=10.0, B=23)   # L=513: the shortest 1024-point frame
 _add("mfcc", 3000, 605, sr=16000.0, fl=10.0, fs=5.0)             # L=160 -> nfft 256

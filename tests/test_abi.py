@@ -135,3 +135,68 @@ def test_plan_create_without_device_fails_loudly(have_gpu, capfd):
     with pytest.raises(api.SpeechError) as e:
         api.Plan("mfcc")
     assert "no HIP device" in str(e.value)
+
+
+def test_release_library_has_no_diagnostic_switches():
+    """the SPEECH_ABLATE timing switches (kernels that skip loads, stores or whole phases) exist only in libspeech_diag.so
+    (make -C speech_amd/csrc diag, -DSPEECH_DIAG): the shipped library neither names the variable nor reads the environment
+    on its launch path.  The one getenv left is host_pipeline.hip's SPEECH_HOST_THREADS (packing threads, read once)."""
+    import subprocess
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"SPEECH_ABLATE" not in blob
+    names = [m.group(0) for m in re.finditer(rb"SPEECH_[A-Z_0-9]+", blob)]
+    assert set(names) <= {b"SPEECH_HOST_THREADS", b"SPEECH_F64"}, set(names)      # SPEECH_F64: the enum's name in HIP_TRY messages
+    # the launch path's translation unit (fast_kernels.o) makes no getenv call at all
+    obj = os.path.join(ROOT, "speech_amd", "csrc", "fast_kernels.o")
+    if os.path.exists(obj):
+        und = subprocess.check_output(["nm", "-u", obj]).decode()
+        assert "getenv" not in und
+
+
+def test_c_sharder_equals_the_python_statement():
+    """speech_shard_utterances (the sharder speech_run_host_multi uses) against api.shard_utterances on ragged lists with
+    ties, single utterances and more shards than utterances"""
+    rng = np.random.default_rng(11)
+    for nutt, world in [(1, 1), (1, 4), (7, 3), (100, 8), (1000, 8), (257, 2), (64, 64), (5, 7)]:
+        n = rng.integers(400, 480001, size=nutt)
+        if nutt > 10:
+            n[::5] = n[0]                                            # ties
+        got = api.shard_assignment(n, world)
+        want = np.full(nutt, -1)
+        for r, idx in enumerate(api.shard_utterances(n, world)):
+            want[idx] = r
+        assert np.array_equal(got, want), (nutt, world)
+    with pytest.raises(api.SpeechError):
+        api.shard_assignment([1, 2, 3], 0)
+
+
+def test_opts_frames_validates_and_sizes_without_a_device(capfd):
+    """speech_opts_frames: W and D in the library's own arithmetic (c/kaldi_mfcc.c:68-78), and the reference's messages"""
+    assert api.opts_frames("mfcc", 160000) == (998, 13)
+    assert api.opts_frames("mfcc", 160000, snip=0) == (1000, 13)
+    assert api.opts_frames("spectrogram", 22050, sr=22050.0) == (1 + (22050 - 551) // 220, 513)
+    assert api.opts_frames("fbank", 16000, B=80, use_energy=1, dtype="f64") == (98, 81)
+    assert api.opts_frames("plp", 100, snip=0) == (1, 13)
+    for N in (400, 401, 559, 560, 561, 16000, 479999):
+        for snip in (0, 1):
+            assert api.opts_frames("mfcc", N, snip=snip)[0] == api.frame_sizes(N, snip_edges=snip)[0]
+    with pytest.raises(api.SpeechError):
+        api.opts_frames("mfcc", 300)
+    assert "error in kaldi_mfcc_s: frame length must be < signal length if snip_edges" in capfd.readouterr().err
+    with pytest.raises(api.SpeechError):
+        api.opts_frames("fbank", 3000, win="kaiser", dtype="f64")
+    assert "error in kaldi_fbank_d: window type must be" in capfd.readouterr().err
+    with pytest.raises(api.SpeechError):
+        api.opts_frames("mfcc", 0, snip=0)
+    assert "N (nsamps in signal) must be positive" in capfd.readouterr().err
+
+
+def test_run_host_multi_rejects_bad_arguments_before_touching_a_device(capfd):
+    x = [np.zeros(2000, dtype=np.float32)]
+    with pytest.raises(api.SpeechError):
+        api.run_host_multi("mfcc", x, [])
+    assert "at least one device" in capfd.readouterr().err
+    with pytest.raises(api.SpeechError):
+        api.run_host_multi("mfcc", x, [0], B=0)
+    assert "error in kaldi_mfcc_s: B (num mel bins) must be positive" in capfd.readouterr().err
+    assert api.run_host_multi("mfcc", [], [0]) == []

@@ -252,6 +252,12 @@ def test_wav_scp_validates_on_cpu(tmp_path):
     assert r.returncode == 1 and "--wav_scp replaces the input file" in r.stderr.decode()
     r = run("kaldi_mfcc", "-d0", "--wav_scp=%s" % (tmp_path / "nolist"), "-o", str(tmp_path / "o.ark"))
     assert r.returncode == 1 and "problem opening the wav_scp file" in r.stderr.decode()
+    # --devices: a comma-separated list of GPU numbers, with --wav_scp only
+    for bad in ("--devices=", "--devices=0,,1", "--devices=a", "--devices=0,-1"):
+        r = run("kaldi_mfcc", "-d0", bad, "--wav_scp=%s" % lst, "-o", str(tmp_path / "o.ark"))
+        assert r.returncode == 1 and "invalid command line" in r.stderr.decode(), bad
+    r = run("kaldi_mfcc", "-d0", "--devices=0,1", str(w), "-o", str(tmp_path / "o.npy"))
+    assert r.returncode == 1 and "--devices goes with --wav_scp" in r.stderr.decode()
 
 
 @pytest.mark.gpu
@@ -283,6 +289,10 @@ def test_wav_scp_to_archive(tmp_path):
     r3 = run("kaldi_fbank", "-g", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f3.ark"))
     assert r.returncode == 0 and r2.returncode == 0 and r3.returncode == 0, r.stderr
     assert (tmp_path / "f.ark").read_bytes() == (tmp_path / "f2.ark").read_bytes() != (tmp_path / "f3.ark").read_bytes()
+    # --devices=0,0: two pipelines inside the library (speech_run_host_multi); the same archive to the byte, dither included
+    r4 = run("kaldi_fbank", "-g", "--seed=11", "--devices=0,0", "--wav_scp=%s" % lst, "-o", str(tmp_path / "f4.ark"))
+    assert r4.returncode == 0, r4.stderr
+    assert (tmp_path / "f4.ark").read_bytes() == (tmp_path / "f.ark").read_bytes()
     r = run("kaldi_mfcc", "-e", "-z", "-y", "-d0", "-b", "40", "-c", "20", "--append", "--wav_scp=%s" % lst, "-o", str(out), "--scp=%s" % scp)
     assert r.returncode == 0, r.stderr
     again = list(ark.read_ark(str(out)))

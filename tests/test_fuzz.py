@@ -83,12 +83,8 @@ def test_random_option_sets_tuned_equals_generic(seed):
         _, ref = O.run(kind, x0, single=True, **o)
         _, ref_fast = O.run(kind, x0, single=True, exact=False, **o)
         truth = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}[kind](np.asarray(x0, dtype=np.float64), single=True, **o)
-        # 1024-point frames: cepstra of many-bin filterbanks sit on the float32 FFT noise floor of the weak high bins, where
-        # three float32 implementations (CPU oracle, generic and tuned kernels) each land 1-3 x the oracle's own distance
-        # from the float64 statement in the MAXIMUM norm (measured over 60 such sets: tuned 0.4-2.8 x, generic 0.6-4 x), hence the
-        # wider bound on the largest deviation there; the rms noise level keeps the suite's margin (compare.MARGIN)
-        ok, e_go, e_gt, e_ot = check_parity(kind, o, got0, ref, truth, tol=1e-5 if kind == "spectrogram" else 1e-4, oracle_fast=ref_fast,
-                                            max_margin=3.0 if o["sr"] >= 32000.0 else 2.0)
+        # the suite's one rule, the suite's one set of margins (compare.MARGIN, MAX_MARGIN, CAP_FACTORS): no per-set widening
+        ok, e_go, e_gt, e_ot = check_parity(kind, o, got0, ref, truth, tol=1e-5 if kind == "spectrogram" else 1e-4, oracle_fast=ref_fast)
         assert ok, (kind, str(o), lens[u0], "hip-vs-oracle %.3g, hip-vs-f64 %.3g, f32-cpu-vs-f64 %.3g" % (e_go, e_gt, e_ot))
         for u, (t, g) in enumerate(zip(*outs)):
             if t.shape[0] == 0:

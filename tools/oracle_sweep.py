@@ -55,7 +55,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
     truth = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}[kind](np.asarray(x, dtype=np.float64), single=single, **{k: v for k, v in o.items() if k != "mn0"})
     if o.get("mn0"): truth = T.mean_norm(truth)
     _, ref_fast = O.run(kind, x, single=single, exact=False, **o)
-    ok, e_go, e_gt, e_ot = check_parity(kind, o, got, ref, truth, tol=(1e-5 if kind == "spectrogram" else 1e-4) if single else 1e-9, oracle_fast=ref_fast, max_margin=3.0)
+    ok, e_go, e_gt, e_ot = check_parity(kind, o, got, ref, truth, tol=(1e-5 if kind == "spectrogram" else 1e-4) if single else 1e-9, oracle_fast=ref_fast)
     if not ok or not np.isfinite(got).all():
         bad += 1; print("PARITY", kind, "single" if single else "double", o, N, "hip-oracle %.3g hip-f64 %.3g oracle-f64 %.3g rms ratio %.3g tuned %s" % (e_go, e_gt, e_ot, compare.PARITY_LOG[-1][6], api.Plan(kind, **{k: v for k, v in o.items() if k != "mn0"}).tuned if single else False), flush=True)
 print("sets", n, "bad", bad)

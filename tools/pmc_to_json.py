@@ -16,6 +16,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech_amd.srchash import kernel_sources_sha  # noqa: E402
+
 CUS, SIMDS, XCDS = 256, 1024, 8
 
 
@@ -51,6 +54,10 @@ def main():
     avg_ns, calls, name = kernel_time_ns(root, kern)
     rec = {"kernel": name, "kernel_avg_ns_under_profiler": avg_ns, "launches": calls, "source": os.path.basename(root.rstrip("/")),
            "command": open(os.path.join(root, "command.txt")).read().strip() if os.path.exists(os.path.join(root, "command.txt")) else None}
+    # what the counters were measured on: the hash of the kernel sources (bench.py nulls the counter fields when the library it
+    # runs was built from other sources) and, when the caller passes it, the commit (the GPU box has no .git)
+    rec["kernel_sources_sha"] = kernel_sources_sha()
+    rec["commit"] = os.environ.get("SPEECH_COMMIT")
     fs, ws = g("fetch", "FETCH_SIZE"), g("write", "WRITE_SIZE")
     if fs is not None and ws is not None:
         rec.update(fetch_size_kib=fs, write_size_kib=ws, hbm_bytes_per_launch=(2.0 * fs + ws) * 1024.0)
@@ -63,12 +70,14 @@ def main():
         rec["wait_frac"] = g("sq", "SQ_WAIT_ANY") / wc
         rec["issue_stall_frac"] = g("sq", "SQ_WAIT_INST_ANY") / wc
         rec["valu_insts_per_launch"] = g("sq", "SQ_INSTS_VALU")
+        rec["shader_clock_ghz"] = cyc / avg_ns if avg_ns else None
     cyc2 = g("sq2", "GRBM_GUI_ACTIVE")
     if cyc2:
         cyc2 /= XCDS
         rec["mfma_util"] = g("sq2", "SQ_VALU_MFMA_BUSY_CYCLES") / (cyc2 * CUS * 4.0)
         rec["mfma_insts_per_launch"] = g("sq2", "SQ_INSTS_MFMA")
         rec["lds_util"] = g("sq2", "SQ_LDS_IDX_ACTIVE") / (cyc2 * CUS)
+        rec["salu_insts_per_launch"] = g("sq2", "SQ_INSTS_SALU")
         if g("sq", "SQ_LDS_BANK_CONFLICT") is not None:
             rec["lds_bank_conflict_frac"] = g("sq", "SQ_LDS_BANK_CONFLICT") / g("sq2", "SQ_LDS_IDX_ACTIVE")
     allj = json.load(open(dst)) if os.path.exists(dst) else {}
