@@ -61,13 +61,16 @@ def window(L, kind):
     raise ValueError(kind)
 
 
+MEAN_HOOK = None      # tools/mean_noise.py: a function frames (W x L, float64) -> W x 1 means, to measure what a float32 mean costs
+
+
 def front_end(x, sr, fl, fs, snip, dc0, preemph, win, single=True, energy_before_dc=False):
     """-> (windowed frames W x L, pre-energy W, post-energy W, nfft)"""
     L, stp, W, nfft = sizes(len(x), sr, fl, fs, snip, single)
     fr = frames(x, L, stp, W, snip)
     e_raw0 = (fr * fr).sum(axis=1)
     if dc0:
-        fr = fr - fr.mean(axis=1, keepdims=True)
+        fr = fr - (MEAN_HOOK(fr) if MEAN_HOOK is not None else fr.mean(axis=1, keepdims=True))
     e_pre = e_raw0 if energy_before_dc else (fr * fr).sum(axis=1)
     if L >= 2 and preemph >= FLT_EPS:
         out = fr.copy()
