@@ -400,6 +400,7 @@ def main():
     ap.add_argument("--nutt", type=int, default=0, help="utterances per GPU (default: the workload's own; rehearsals on one GPU need fewer)")
     ap.add_argument("--corpus-hours", type=float, default=1250.0, help="size of the wave-streamed hires-MFCC corpus leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / other workloads (profiling runs)")
+    ap.add_argument("--no-check", action="store_true", help="skip the check of the timed output (only for libspeech_diag.so runs whose kernels skip phases on purpose)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -492,7 +493,8 @@ def main():
         k_iso, k_min = work.kernel_ms(stream)
         achieved = work.bytes / (k_avg * 1e-3) / 1e9
         u = utilisation(args.workload)
-        check = output_check(work)                                     # what the timed launches wrote, before anything overwrites it
+        # what the timed launches wrote, before anything overwrites it (skipped only on request, and the line says so)
+        check = {"skipped": True, "ok": None, "vs_oracle": []} if args.no_check else output_check(work)
         # compute-side figure: SURVEY.md 8(d)'s algorithmic flop (sparse mel, real FFT as 2.5 n log2 n) against the f32 vector peak
         o_ = work.opts
         flop_frame = ALG_FLOP_PER_FRAME[work.kind] + (2.0 * o_.get("B", 23) * o_.get("C", 13) if work.kind == "mfcc" else 0.0)
@@ -516,7 +518,7 @@ def main():
             "per_gpu": [{"rank": r, "audio_s_per_s": p[1] * args.steps / p[0], "kernel_ms_avg": p[2], "audio_s": p[1],
                          "roofline_frac_hbm": p[3] / (p[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "device": infos[r]} for r, p in enumerate(per)],
         }
-        if not check["ok"]:
+        if check["ok"] is False:
             sys.stderr.write("bench.py: the timed output FAILED its check: %s\n" % json.dumps(check))
         if not args.no_extras and world == 1:       # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(work)
@@ -552,7 +554,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
-        if not out["output_check"]["ok"]:
+        if out["output_check"]["ok"] is False:
             sys.exit(3)                                                # a bench line whose output failed its check is not a result
 
 

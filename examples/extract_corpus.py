@@ -11,7 +11,8 @@ out_dir/feats.<rank>.<wave>.ark + .scp, record the wave in out_dir/manifest.<ran
 the shard; a run that was killed resumes after its last recorded wave.  With --cmvn the ranks add their per-feature sums
 (kept per wave in the manifest) with ONE all-reduce of 2 D + 1 doubles (api.merge_stats: RCCL, or gloo when the ranks share
 a GPU) and write out_dir/cmvn.npz (scale, offset: y = x * scale + offset, what Kaldi's apply-cmvn does from its stats
-file); --apply-cmvn then rewrites the archives normalised, again one wave at a time.  Without a launcher it runs as a single
+file); --apply-cmvn then writes normalised copies feats_cmvn.<rank>.<wave>.ark beside the archives, again one wave at a time
+(the extracted archives are never modified, so this step, too, can be killed and repeated).  Without a launcher it runs as a single
 rank."""
 import argparse
 import os
@@ -29,7 +30,7 @@ def main():
     ap.add_argument("out_dir")
     ap.add_argument("--kind", default="mfcc", choices=["spectrogram", "fbank", "mfcc", "plp"])
     ap.add_argument("--cmvn", action="store_true", help="corpus-wide mean / variance normalisation")
-    ap.add_argument("--apply-cmvn", action="store_true", help="with --cmvn: rewrite the archives normalised")
+    ap.add_argument("--apply-cmvn", action="store_true", help="with --cmvn: write normalised copies feats_cmvn.* beside the archives")
     ap.add_argument("--wave-mb", type=int, default=1024, help="audio read, extracted and written at a time, MiB of .wav files")
     ap.add_argument("--opt", action="append", default=[], help="plan option, name=value (e.g. B=40, dither=1.0, snip_edges=0)")
     a = ap.parse_args()
@@ -71,17 +72,9 @@ def main():
         if rank == 0:
             np.savez(os.path.join(a.out_dir, "cmvn.npz"), scale=scale, offset=offset, frames=n)
         if a.apply_cmvn:
-            for path in res["arks"]:                                           # one wave's archive at a time
-                feats = [(k, (m * scale.astype(m.dtype)).astype(m.dtype) + offset.astype(m.dtype)) for k, _, m in ark.read_ark(path)]
-                scp = path[:-4] + ".scp"
-                open(scp + ".tmp", "w").close()
-                ark.write_ark(path + ".tmp", feats, scp=scp + ".tmp")
-                with open(scp + ".tmp") as f:
-                    lines = f.read().replace(path + ".tmp", path)
-                with open(scp, "w") as f:
-                    f.write(lines)
-                os.remove(scp + ".tmp")
-                os.replace(path + ".tmp", path)
+            # normalised copies beside the extracted archives (feats_cmvn.<rank>.<wave>.ark + .scp), one wave at a time; the
+            # extracted archives stay as they are, so a run killed in this loop and started again normalises nothing twice
+            corpus.apply_cmvn_to_archives(res["arks"], scale, offset)
 
     if world > 1:
         import torch.distributed as dist

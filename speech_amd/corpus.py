@@ -226,9 +226,45 @@ def run_synthetic(spec, kind, opts, device=0, wave_audio_s=1.0e6, out_dir=None, 
     ran, skipped = walk(waves, man, do_wave, exists if out_dir else None)
     torch.cuda.synchronize()
     plan.close()
+    # Totals are whole-corpus figures, built from the manifest's records like run_files does (a resumed run skips finished
+    # waves: their samples, frames and kernel times come from the lines the earlier run wrote); what THIS call ran is kept
+    # beside them as *_run_now, so that a rate computed after a resume says which part it covers.
+    recs = [man.done[w] for w in sorted(man.done) if w < len(waves)]
+    run_now = dict(tot)
+    for k in ("kernel_ms", "generate_ms", "samples", "features", "frames", "utterances"):
+        tot[k] = type(run_now[k])(sum(r.get(k, 0) for r in recs))
+        tot[k + "_run_now"] = run_now[k]
     tot.update(waves=len(waves), waves_run=ran, waves_skipped=skipped, wall_s=time.perf_counter() - t0, audio_s=tot["samples"] / float(spec.sr),
-               manifest=mpath, records=[man.done[w] for w in sorted(man.done)])
+               audio_s_run_now=run_now["samples"] / float(spec.sr), manifest=mpath, records=recs)
     return tot
+
+
+def apply_cmvn_to_archives(arks, scale, offset, _after_each=None):
+    """Write every archive of `arks` (feats.<rank>.<wave>.ark) normalised, y = x * scale + offset, as feats_cmvn.<rank>.<wave>.ark
+    + .scp BESIDE it.  The extracted archives are never modified, so the step can be killed and run again any number of times:
+    a normalised archive is always computed from the raw one (never from an already normalised one), written under a
+    temporary name and renamed.  Returns the normalised archives' paths.  _after_each(i): test hook, called after archive i."""
+    from . import ark
+    out = []
+    for i, path in enumerate(arks):
+        d, base = os.path.dirname(path), os.path.basename(path)
+        if not base.startswith("feats."):
+            raise ValueError("unexpected archive name %s" % path)
+        dst = os.path.join(d, "feats_cmvn." + base[len("feats."):])
+        feats = [(k, (m * scale.astype(m.dtype)).astype(m.dtype) + offset.astype(m.dtype)) for k, _, m in ark.read_ark(path)]
+        scp = dst[:-4] + ".scp"
+        open(scp + ".tmp", "w").close()
+        ark.write_ark(dst + ".tmp", feats, scp=scp + ".tmp")
+        with open(scp + ".tmp") as f:
+            lines = f.read().replace(dst + ".tmp", dst)
+        with open(scp + ".tmp", "w") as f:
+            f.write(lines)
+        os.replace(scp + ".tmp", scp)
+        os.replace(dst + ".tmp", dst)
+        out.append(dst)
+        if _after_each is not None:
+            _after_each(i)
+    return out
 
 
 def read_wav16(path):

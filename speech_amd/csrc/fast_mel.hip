@@ -146,6 +146,13 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
     const int fq = wv * FWK;                                                // the wave's first frame within the sub-tile
+    // the wave's span of audio for the sub-tile at tile-relative frame fb (nf frames) into its slice: buffer_load ... lds where the
+    // span allows it (asynchronous: the barrier that follows waits for it), else through registers (fast_common.hpp load_span)
+    auto load_quad = [&](const int fb, const int nf) {
+        const long long w0 = (long long)tile.frame0 + fb + fq;
+        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
+        if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nf - 1) * p.stp + p.L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (p.ws & ~255));
+    };
     for (int sub = 0; sub < NSUB; ++sub)
     {
     const int fbase = sub * TILEK;                                          // the sub-tile's first frame within the tile
@@ -155,12 +162,9 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     const float *s_tab_l = (NSUB > 1) ? s_tab + opaque_zero() : s_tab;
     if (sub > 0 && fbase >= (int)tile.nframes) { break; }                   // (uniform) a short last tile
     const int nfr = min((int)tile.nframes - fbase - fq, FWK);
-    if (nfr > 0)
-    {
-        const long long w0 = (long long)tile.frame0 + fbase + fq;
-        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
-        if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (p.ws & ~255));
-    }
+    // the wave's audio for this sub-tile.  plp's later sub-tiles: requested at the end of the sub-tile before (below), ahead of
+    // the IDFT job, so that the two waves that run that job do not start their loads -- and hold up the barrier -- after it
+    if (sub == 0 && nfr > 0) { load_quad(fbase, nfr); }
     __syncthreads();
 
     const int f = lane >> 4, k2 = lane & 15;
@@ -212,6 +216,10 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t0]), 0, (wv < njob_m) ? 256 * p.mel_ksteps[t0] : 0, BUF_FLAGS);
         weights_issue(wpre, rb, lane_m * 4, 256);
     }
+    // plp: the equal-loudness factor of the lane's mel bin in the wave's first job travels with the weights (read in the job's
+    // epilogue it was a dependent L2 access per job with nothing to hide behind: the mel phase of plp cost 1.66 x mfcc's)
+    float eqv = 0.0f;
+    if (KIND == SPEECH_PLP && wv < njob_m) { const int t0 = wv / RTK; if (col < p.mel_cnt[t0]) { eqv = p.aux[p.mel_first[t0] + col]; } }
 
     // The power tile takes the slices' place.  When a slice is exactly as long as the wave's rows of the tile (the usual
     // case: ws = FWK * PPK), a wave's rows lie in its own slice and it only has to be done with its own transposition image.
@@ -324,6 +332,8 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         }
         const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
         const bool live_c = col < p.mel_cnt[t];
+        const float eq = eqv;                                               // plp: this job's equal-loudness factor; the next job's is requested now
+        if (KIND == SPEECH_PLP && job + MW < njob_m) { const int tn = (job + MW) / RTK; eqv = (col < p.mel_cnt[tn]) ? p.aux[p.mel_first[tn] + col] : 0.0f; }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
                 // equal loudness, compression, end duplication (c/kaldi_plp.c:339-358)
                 if (live)
                 {
-                    const float x = v * p.aux[m];
+                    const float x = v * eq;
                     const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : pow_split(x, p.compress));
                     s_mel[fr * p.MP + 1 + m] = c;
                     if (m == 0) { s_mel[fr * p.MP] = c; }
@@ -380,6 +390,14 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     }
     if (KIND == SPEECH_PLP)
     {
+        // The power tile (= the slices) is dead since the barrier above: the NEXT sub-tile's audio goes on its way now, before
+        // the IDFT job that only waves 0 .. RTK-1 have (their loads used to start after it, one exposed memory latency per
+        // sub-tile for the whole workgroup, which waits for them at the next barrier).  The IDFT reads s_mel and writes s_ac.
+        if (NSUB > 1 && sub + 1 < NSUB)
+        {
+            const int nfn = min((int)tile.nframes - (fbase + TILEK) - fq, FWK);
+            if (nfn > 0) { load_quad(fbase + TILEK, nfn); }
+        }
         // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames
         if (wv < RTK)
         {

@@ -130,6 +130,12 @@ def test_corpus_waves_resume_and_match_the_oracle(tmp_path):
     assert r2["waves_skipped"] == 2 and r2["waves_run"] == r2["waves"] - 2 and r2["waves"] >= 5
     r3 = corpus.run_synthetic(spec, "mfcc", opts, wave_audio_s=100.0, out_dir=out)
     assert r3["waves_run"] == 0
+    # totals are whole-corpus figures whatever was run now (from the manifest's records); *_run_now says what this call did
+    total = int(spec.lens.sum())
+    assert r1["samples"] == r1["samples_run_now"] < total
+    assert r2["samples"] == r3["samples"] == total and r2["samples_run_now"] == total - r1["samples"] and r3["samples_run_now"] == 0
+    assert r3["utterances"] == spec.lens.size and r3["kernel_ms"] > 0.0 and r3["kernel_ms_run_now"] == 0.0
+    assert abs(r3["audio_s"] - total / 16000.0) < 1e-6 and r3["audio_s_run_now"] == 0.0
     with pytest.raises(ValueError):
         corpus.run_synthetic(spec, "mfcc", dict(opts, B=41), wave_audio_s=100.0, out_dir=out)
     feats = {}
@@ -202,3 +208,47 @@ def test_file_corpus_streams_in_waves_and_resumes(tmp_path):
     r0 = corpus.run_files(keys, paths, "mfcc", {"B": 23}, str(tmp_path / "two"), rank=0, world=2, wave_bytes=9000, extract=extract)
     r1 = corpus.run_files(keys, paths, "mfcc", {"B": 23}, str(tmp_path / "two"), rank=1, world=2, wave_bytes=9000, extract=extract)
     assert r0["utterances"] + r1["utterances"] == 7 and np.allclose(r0["sum"] + r1["sum"], res["sum"])
+
+
+def test_apply_cmvn_can_be_killed_and_repeated(tmp_path):
+    """round-2 advisor finding: --apply-cmvn used to rewrite the extracted archives in place, so a run killed in that loop and
+    started again normalised the already rewritten ones twice.  The normalised features now go to feats_cmvn.* beside the
+    archives, always computed from the untouched extracted ones: kill after the first archive, run again, every normalised
+    archive is x * scale + offset exactly once"""
+    from speech_amd import ark
+    rng = np.random.default_rng(4)
+    D = 5
+    raw, arks = {}, []
+    for w in range(3):
+        feats = [("utt%d_%d" % (w, i), rng.standard_normal((int(rng.integers(3, 9)), D)).astype(np.float32) * 10 + 3) for i in range(4)]
+        path = str(tmp_path / ("feats.0.%d.ark" % w))
+        ark.write_ark(path, feats)
+        raw.update(dict(feats))
+        arks.append(path)
+    before = {p: open(p, "rb").read() for p in arks}
+    scale, offset = rng.uniform(0.5, 2.0, D), rng.uniform(-1.0, 1.0, D)
+
+    class Killed(Exception):
+        pass
+
+    def kill_after_first(i):
+        if i == 0:
+            raise Killed()
+
+    with pytest.raises(Killed):
+        corpus.apply_cmvn_to_archives(arks, scale, offset, _after_each=kill_after_first)
+    assert os.path.exists(tmp_path / "feats_cmvn.0.0.ark") and not os.path.exists(tmp_path / "feats_cmvn.0.1.ark")
+    out = corpus.apply_cmvn_to_archives(arks, scale, offset)            # the resumed run
+    out2 = corpus.apply_cmvn_to_archives(arks, scale, offset)           # and once more for good measure
+    assert out == out2 == [str(tmp_path / ("feats_cmvn.0.%d.ark" % w)) for w in range(3)]
+    assert {p: open(p, "rb").read() for p in arks} == before            # the extracted archives were never touched
+    seen = {}
+    for p in out:
+        for (k, _, m), (k2, m2) in zip(ark.read_ark(p), ark.read_scp(p[:-4] + ".scp")):
+            assert k == k2 and np.array_equal(m, m2)
+            seen[k] = m
+    assert set(seen) == set(raw)
+    for k, m in seen.items():
+        want = (raw[k] * scale.astype(np.float32)).astype(np.float32) + offset.astype(np.float32)
+        assert np.array_equal(m, want), k
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]

@@ -105,13 +105,13 @@ def test_corpus_extraction_two_ranks_on_the_gpu(tmp_path):
     assert r2.returncode == 0, r2.stderr.decode()[-2000:]
     import glob
     one = {}
-    for path in sorted(glob.glob(str(tmp_path / "one" / "feats.0.*.ark"))):
+    for path in sorted(glob.glob(str(tmp_path / "one" / "feats_cmvn.0.*.ark"))):      # --apply-cmvn: normalised copies beside the extracted archives
         one.update({k: m for k, _, m in ark.read_ark(path)})
     assert len(glob.glob(str(tmp_path / "one" / "feats.0.*.ark"))) == 7       # seven waves of one utterance
     two = {}
     for rank in (0, 1):
         part = {}
-        for scp in sorted(glob.glob(str(tmp_path / "two" / ("feats.%d.*.scp" % rank)))):
+        for scp in sorted(glob.glob(str(tmp_path / "two" / ("feats_cmvn.%d.*.scp" % rank)))):
             part.update({k: m for k, m in ark.read_scp(scp)})
         assert part and not (set(part) & set(two))
         two.update(part)

@@ -1,5 +1,5 @@
 #!/bin/bash
 # where a mel-kind kernel's time goes: stop after the FFT (4), the power tile (32), the mel contraction (64), or run it all (0)
 # tools/ablate_mel.sh workload...
-for w in "$@"; do for a in 4 32 64 0; do SPEECH_ABLATE=$a timeout -k 10 100 python bench.py --no-extras --steps 20 --workload $w 2>/dev/null | python -c "
+for w in "$@"; do for a in 4 32 64 0; do SPEECH_AMD_LIB=$PWD/speech_amd/lib/libspeech_diag.so SPEECH_ABLATE=$a timeout -k 10 100 python bench.py --no-extras --no-check --steps 20 --workload $w 2>/dev/null | python -c "
 import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('$w ablate $a', 'sustained', round(r['kernel_ms_avg'],4), 'isolated', round(r['kernel_ms_isolated_avg'],4))" || exit 1; done; done
