@@ -57,7 +57,6 @@ constexpr int MW = 8;                   // waves per workgroup, mel kinds: with 
                                         // per mel tile, i.e. a job for every wave, and half as many workgroup barriers per frame
 constexpr int NTM = 64 * MW;            // threads per workgroup, mel kinds
 
-constexpr int PLP_TAIL_FRAMES = 128;    // plp: frames per workgroup (sub-tiles of MW x frames-per-wave); the serial tail runs once, one lane per frame (two waves)
 constexpr int TILE_SPEC = 64;  // frames per workgroup, spectrogram: 4 sub-tiles of 16 frames, one quad per wave per sub-tile
 constexpr int NPRE = 16;                // prefetch registers per lane: the next quad's audio (up to 1024 samples)
 constexpr int TR_WAVE_C = 2048;         // floats of a wave's slice when the transposition image is complex (spectrogram kernel)
@@ -102,6 +101,7 @@ struct FastParams {
     const float *tab;
     // mel kinds
     const float *melw, *mat2, *aux;
+    float *plp_en;                      // plp with use_energy: the batch's energy scratch, one float per output row (row = y_off / C + frame)
     int B, C, MP, Cp, K2, ntile_m, ntile_c;
     int m2;                             // floats of mat2 staged in LDS between the tables and the slices (0: not staged)
     int amp, lg, use_energy, compress_mode;
@@ -118,6 +118,16 @@ struct FastParams {
 #endif
 
 typedef void (*kernel_fn)(const FastParams);
+
+// plp's second launch (fast_mel.hip, plp_tail_kernel): rows of autocorrelations -> cepstra, in place
+struct PlpTailParams {
+    float *Y;
+    const UttDesc *utts;
+    const float *aux;                   // eql[B] | lift[C]
+    const float *en;                    // frame energies (use_energy), row = y_off / C + frame
+    int B, C, use_energy;
+};
+hipError_t launch_plp_tail(const PlpTailParams &q, uint32_t nutt, uint32_t max_frames, hipStream_t s);
 // the instantiation that serves a plan: nz = rows of samples that hold data (9..16), pair = two frames per transform
 kernel_fn fast_spectrogram_kernel_for(int nz, bool dither, bool pcm, bool pair, bool wide, bool xwide);   // fast_spectrogram.hip
 kernel_fn fast_mel_kernel_for(int nz, int kind, bool dither, bool pair, bool wide, bool xwide);   // fast_mel.hip
@@ -302,6 +312,9 @@ __device__ __forceinline__ float pow_split(float x, float c)
 }
 #ifndef PLP_IEEE_DIV
 #define PLP_IEEE_DIV 1
+#endif
+#ifndef PLP_POW_SPLIT
+#define PLP_POW_SPLIT 1                 // 0: exp2(c log2 x) on the whole value (rounds 1-2), for A/B timing and noise measurements
 #endif
 
 // spectrogram: log(max(q / 4, FLT_EPSILON)) for q = 4 |X|^2, exponent and mantissa split as in pos_log: v_log_f32 on the

@@ -52,16 +52,16 @@ static FastGeom fast_geom(const speech_opts &o, size_t L, size_t nfft)
     {
         const size_t P = (o.lpc_order > 0u) ? o.lpc_order : o.C - 1u;
         if (P != 12u) { return g; }                                         // the in-register Levinson-Durbin is built for order 12
+        if (o.C < P + 1u) { return g; }                                     // the frame's output row carries r[0..12] between the two launches
         D = o.C; cols = (o.B + 2u + 3u) & ~(size_t)3;
     }
     const size_t T = (size_t)MW * (size_t)g.fw;                             // frames per sub-tile: one pass of the workgroup
-    const size_t nsub = (o.kind == SPEECH_PLP) ? (size_t)PLP_TAIL_FRAMES / T : 1u;      // plp: sub-tiles per workgroup (fast_mel.hip)
+    const size_t nsub = 1u;
     g.tile = (int)(T * nsub);
     g.ws = std::max(g.span, g.xwide ? (T * PPX + MW - 1) / MW : (g.wide ? (T * PPW + MW - 1) / MW : (g.pair ? (T * PP2 + MW - 1) / MW : (size_t)TR_WAVE)));     // the slices together hold the power tile
     // behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile | plp: autocorrelations; the mfcc / plp
     // output tile reuses the power tile's place
-    const size_t extra = T * nsub + (o.kind == SPEECH_FBANK ? ((T * D + 3u) & ~(size_t)3) : T * (size_t)mel_pitch((int)cols))
-                         + (o.kind == SPEECH_PLP ? T * nsub * 17u : 0u);
+    const size_t extra = T * nsub + (o.kind == SPEECH_FBANK ? ((T * D + 3u) & ~(size_t)3) : T * (size_t)mel_pitch((int)cols));
     if (T * nsub * D > (size_t)MW * g.ws) { return g; }
     g.ws = (g.ws + 3u) & ~(size_t)3;                                         // slices stay 16-byte aligned
     g.lds = (tabf + MW * g.ws + extra) * sizeof(float);
@@ -269,7 +269,7 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, hipStr
     { const char *ab = getenv("SPEECH_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }     // libspeech_diag.so only: timing diagnostics, DESIGN.md 4.3
 #endif
     p.tab = t->d_tab;
-    p.melw = t->d_melw; p.mat2 = t->d_mat2; p.aux = t->d_aux;
+    p.melw = t->d_melw; p.mat2 = t->d_mat2; p.aux = t->d_aux; p.plp_en = fp.plp_en;
     p.B = t->B; p.C = t->C; p.MP = t->MP; p.Cp = t->Cp; p.K2 = t->K2; p.ntile_m = t->ntile_m; p.ntile_c = t->ntile_c;
     p.amp = fp.amp; p.lg = fp.lg; p.use_energy = fp.use_energy; p.compress_mode = fp.compress_mode; p.compress = fp.compress;
     for (int i = 0; i < MAX_MTILES; ++i) { p.mel_kbeg[i] = t->mel_kbeg[i]; p.mel_ksteps[i] = t->mel_ksteps[i]; p.mel_woff[i] = t->mel_woff[i]; p.mel_first[i] = t->mel_first[i]; p.mel_cnt[i] = t->mel_cnt[i]; }
@@ -281,6 +281,14 @@ hipError_t launch_fast(const FastTables *t, const FrameParams<float> &fp, hipStr
     hipLaunchKernelGGL(k, dim3(fp.ntiles), dim3(mel ? NTM : NT), lds, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) { return e; }
+    if (t->kind == SPEECH_PLP)                                              // second launch: autocorrelation rows -> cepstra, in place
+    {
+        if (fp.use_energy && !fp.plp_en) { return hipErrorInvalidValue; }
+        PlpTailParams q;
+        q.Y = fp.Y; q.utts = fp.utts; q.aux = t->d_aux; q.en = fp.plp_en; q.B = t->B; q.C = t->C; q.use_energy = fp.use_energy;
+        e = launch_plp_tail(q, fp.nutt, fp.max_frames, s);
+        if (e != hipSuccess) { return e; }
+    }
     if (ev1) { e = hipEventRecord(ev1, s); }
     return e;
 }

@@ -116,11 +116,11 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     constexpr int TILEK = MW * FWK;                                         // frames per workgroup
     constexpr int RTK = XW ? 1 : TILEK / 16;                                // 16-frame row tiles
     constexpr int PPK = XW ? PPX : (WIDE ? PPW : (PAIR ? PP2 : PP));        // pitch of the power tile
-    // plp: the workgroup walks NSUB sub-tiles of TILEK frames through the FFT, mel and IDFT phases and only then runs the
-    // serial tail (Levinson-Durbin, one lane per frame) once, on 128 frames: two full waves instead of a half or quarter one
-    // per 32 or 16 frames, one barrier pair less per sub-tile, and the tail's latency (the other six waves wait for it) paid
-    // once per 128 frames (64 -> 128: -2 %; both frames of a lane pair in packed-f32 registers on one wave: no better)
-    constexpr int NSUB = (KIND == SPEECH_PLP) ? PLP_TAIL_FRAMES / TILEK : 1;
+    // plp runs in TWO launches: this kernel stops at the autocorrelations r[0..12] (written to the frame's output row, which has
+    // C >= 13 columns), plp_tail_kernel below turns every row into cepstra in place, one lane per frame over dense waves.
+    // (Rounds 1-2 ran Levinson-Durbin inside this kernel -- one lane per frame of a 32-frame tile, later of four sub-tiles =
+    // 128 frames walked in a loop; workgroups that loop run their phases in step and lose what staggered one-tile workgroups
+    // gain from each other: plp cost mfcc + 14-16 %.)
     constexpr int TABK = XW ? TABX_TWF : (WIDE ? TABW_FLOATS : TAB_FLOATS);        // floats of tables in front of the slices (2048-point plans: the twiddles; the window stays in memory)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -137,8 +137,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     // tile (and plp's autocorrelations) are written after the power tile is dead and reuse its place.
     float *s_e = s_sl + MW * p.ws;
     float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILEK : s_pow;
-    float *s_mel = s_e + NSUB * TILEK;
-    float *s_ac = s_mel + TILEK * p.MP;                                     // plp: [NSUB * TILEK][17] autocorrelations, kept across the sub-tiles
+    float *s_mel = s_e + TILEK;
     // tables (and the staged matrix) in 16-byte units: one load per thread in flight instead of a loop of load - wait - store
     for (int i = tid; i < TABK / 4; i += NTM) { reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(p.tab)[i]; }
     for (int i = tid; i < p.m2 / 4; i += NTM) { reinterpret_cast<float4 *>(s_m2)[i] = reinterpret_cast<const float4 *>(p.mat2)[i]; }
@@ -146,26 +145,16 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
     const int fq = wv * FWK;                                                // the wave's first frame within the sub-tile
-    // the wave's span of audio for the sub-tile at tile-relative frame fb (nf frames) into its slice: buffer_load ... lds where the
-    // span allows it (asynchronous: the barrier that follows waits for it), else through registers (fast_common.hpp load_span)
-    auto load_quad = [&](const int fb, const int nf) {
-        const long long w0 = (long long)tile.frame0 + fb + fq;
-        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
-        if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nf - 1) * p.stp + p.L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (p.ws & ~255));
-    };
-    for (int sub = 0; sub < NSUB; ++sub)
+    const int nfr = min((int)tile.nframes - fq, FWK);
+    if (nfr > 0)
     {
-    const int fbase = sub * TILEK;                                          // the sub-tile's first frame within the tile
-    // what the body derives from the lane number and reads from the tables (twiddles, window: some 70 registers' worth) is
-    // loop-invariant; hoisted out of the sub-tile loop it would cost a resident workgroup per CU, so both are made opaque here
-    if (NSUB > 1) { asm volatile("" : "+v"(lane)); }
-    const float *s_tab_l = (NSUB > 1) ? s_tab + opaque_zero() : s_tab;
-    if (sub > 0 && fbase >= (int)tile.nframes) { break; }                   // (uniform) a short last tile
-    const int nfr = min((int)tile.nframes - fbase - fq, FWK);
-    // the wave's audio for this sub-tile.  plp's later sub-tiles: requested at the end of the sub-tile before (below), ahead of
-    // the IDFT job, so that the two waves that run that job do not start their loads -- and hold up the barrier -- after it
-    if (sub == 0 && nfr > 0) { load_quad(fbase, nfr); }
+        const long long w0 = (long long)tile.frame0 + fq;
+        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
+        if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (p.ws & ~255));
+    }
     __syncthreads();
+    const float *s_tab_l = s_tab;
+    constexpr int fbase = 0;
 
     const int f = lane >> 4, k2 = lane & 15;
     float pa[9], pb[9], rawe = 1.0f;
@@ -354,7 +343,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
                 if (live)
                 {
                     const float x = v * eq;
-                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : pow_split(x, p.compress));
+                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : (PLP_POW_SPLIT ? pow_split(x, p.compress) : __builtin_amdgcn_exp2f(p.compress * __log2f(x))));
                     s_mel[fr * p.MP + 1 + m] = c;
                     if (m == 0) { s_mel[fr * p.MP] = c; }
                     if (m == p.B - 1) { for (int j = p.B + 1; j < p.K2; ++j) { s_mel[fr * p.MP + j] = (j == p.B + 1) ? c : 0.0f; } }
@@ -390,75 +379,22 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     }
     if (KIND == SPEECH_PLP)
     {
-        // The power tile (= the slices) is dead since the barrier above: the NEXT sub-tile's audio goes on its way now, before
-        // the IDFT job that only waves 0 .. RTK-1 have (their loads used to start after it, one exposed memory latency per
-        // sub-tile for the whole workgroup, which waits for them at the next barrier).  The IDFT reads s_mel and writes s_ac.
-        if (NSUB > 1 && sub + 1 < NSUB)
-        {
-            const int nfn = min((int)tile.nframes - (fbase + TILEK) - fq, FWK);
-            if (nfn > 0) { load_quad(fbase + TILEK, nfn); }
-        }
-        // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames
+        // autocorrelation = IDFT bases x compressed spectrum, one MFMA tile per 16 frames.  The
+        // power tile is dead since the barrier above: r[0..12] of frame fr goes to columns 0..12 of its output row (C >= 13;
+        // plp_tail_kernel rewrites the whole row), the frame's energy -- when it is used -- to the batch's energy scratch
         if (wv < RTK)
         {
             const float *arow = s_mel + (16 * wv + (XW ? (col & 7) : col)) * p.MP + (lane_m >> 4);
             const f32x4 acc = p.m2 ? mfma_tile(arow, s_m2 + lane_m, 64, ks2) : mfma_tile(arow, p.mat2 + lane_m, 64, ks2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { if (!XW || fr0 + r < TILEK) { s_ac[(fbase + 16 * wv + fr0 + r) * 17 + col] = acc[r]; } }
+            for (int r = 0; r < 4; ++r) { if (col <= P && (!XW || fr0 + r < TILEK)) { s_out[(16 * wv + fr0 + r) * p.C + col] = acc[r]; } }
         }
-    }
-    }   // sub-tiles
-    if (KIND == SPEECH_PLP)
-    {
-        __syncthreads();
-        if (tid < NSUB * TILEK)
+        if (p.use_energy && tid < (int)tile.nframes)
         {
-            // one lane per frame: Levinson-Durbin with Kaldi's 1 - k^2 >= 1e-5 guard, LPC -> cepstrum, lifter
-            // (reference intent c/kaldi_plp.c:206,380-403)
-            const float *r = s_ac + tid * 17;
-            float a[P > 0 ? P : 1], tmp[P > 0 ? P : 1], cep[P > 0 ? P : 1];
-            float E = r[0];
-#pragma unroll
-            for (int i = 0; i < P; ++i)
-            {
-                float ki = r[i + 1];
-#pragma unroll
-                for (int j = 0; j < i; ++j) { ki += a[j] * r[i - j]; }
-                ki = PLP_IEEE_DIV ? ki / E : ki * fast_rcp(E);              // the oracle's (and Kaldi's) k /= E
-                float c = 1.0f - ki * ki;
-                c = (c < 1.0e-5f) ? 1.0e-5f : c;
-                E *= c;
-                tmp[i] = -ki;
-#pragma unroll
-                for (int j = 0; j < i; ++j) { tmp[j] = a[j] - ki * a[i - j - 1]; }
-#pragma unroll
-                for (int j = 0; j <= i; ++j) { a[j] = tmp[j]; }
-            }
-#pragma unroll
-            for (int i = 0; i < P; ++i)
-            {
-                float sum = 0.0f;
-#pragma unroll
-                for (int j = 0; j < i; ++j) { sum += (float)(i - j) * a[j] * cep[i - j - 1]; }
-                cep[i] = -a[i] - sum * (1.0f / (float)(i + 1));
-            }
-            const float *lift = p.aux + p.B;
-            float *y = s_out + tid * p.C;
-            const int C = p.C;
-            float prev = 0.0f;
-#pragma unroll
-            for (int k = 0; k <= P; ++k)
-            {
-                if (k < C)
-                {
-                    float v = (k == 0) ? floor_log(E) : cep[k > 0 ? k - 1 : 0];
-                    v *= lift[k];
-                    if (k == 0 && p.use_energy) { v = pos_log(s_e[tid]); }     // c/kaldi_plp.c:397
-                    if (k == C - 1 && C >= 2) { v = prev; }                                               // c/kaldi_plp.c:403
-                    y[k] = v; prev = v;
-                }
-            }
-            for (int k = P + 1; k < C; ++k) { const float v = (k == C - 1) ? prev : 0.0f; y[k] = v; prev = v; }
+            // row number of the utterance's first frame in the energy scratch: y_off / C (exact in double for any offset below 2^53)
+            unsigned long long q = (unsigned long long)((double)utt.y_off / (double)p.C);
+            if (q * (unsigned long long)p.C > utt.y_off) { --q; } else if ((q + 1ull) * (unsigned long long)p.C <= utt.y_off) { ++q; }
+            p.plp_en[q + tile.frame0 + (unsigned)tid] = s_e[tid];
         }
         __syncthreads();
     }
@@ -512,6 +448,100 @@ kernel_fn mel_xwide_for_nz(int nz, int kind)
 kernel_fn fast_mel_xwide_kernel_for(int nz, int kind, bool dither) { return dither ? mel_xwide_for_nz<true>(nz, kind) : mel_xwide_for_nz<false>(nz, kind); }
 
 #else
+// plp, second launch: every frame's row holds r[0..12] (columns 0..P of its C >= P + 1 columns); one lane per frame turns it
+// into the cepstra in place -- Levinson-Durbin with Kaldi's 1 - k^2 >= 1e-5 guard, LPC -> cepstrum, lifter, in the oracle's
+// sequential order (reference intent c/kaldi_plp.c:206,380-403).  The recursions are ~500
+// dependent instructions per frame whatever the lane count, so one lane per frame over full waves is the issue-optimal shape;
+// a workgroup takes TAIL_FRAMES consecutive frames of one utterance, whose rows are one contiguous run of Y: they come in and
+// go out as whole cache lines through LDS (element i of the run lives at i + i / 32: a lane walks its row at stride C, and
+// the padding keeps that conflict-free for even C as well).
+constexpr int TAIL_FRAMES = 128;
+
+// (Two frames per lane in packed-f32 registers halve the instruction count and change nothing -- 30.1 against 28.9 us for
+// 1 000 x 10 s: the launch moves 2 x 52 MB in that time, i.e. it costs what its traffic costs.)
+template <int P>
+__global__ __launch_bounds__(TAIL_FRAMES) void plp_tail_kernel(const PlpTailParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];
+    const UttDesc utt = q.utts[blockIdx.x];
+    const long long W = (long long)utt.W;
+    const long long row0 = (long long)blockIdx.y * TAIL_FRAMES;
+    if (row0 >= W) { return; }
+    const int tid = threadIdx.x, C = q.C;
+    const int nr = (int)min((long long)TAIL_FRAMES, W - row0);
+    float *y = q.Y + utt.y_off + (unsigned long long)row0 * (unsigned long long)C;
+    const int n = nr * C;
+    for (int i = tid; i < n; i += TAIL_FRAMES) { s_rows[i + (i >> 5)] = y[i]; }
+    __syncthreads();
+    if (tid < nr)
+    {
+        const int base = tid * C;
+        float a[P], tmp[P], cep[P], r[P + 1];
+#pragma unroll
+        for (int i = 0; i <= P; ++i) { r[i] = s_rows[base + i + ((base + i) >> 5)]; }
+        float E = r[0];
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+        {
+            float ki = r[i + 1];
+#pragma unroll
+            for (int j = 0; j < i; ++j) { ki += a[j] * r[i - j]; }
+            ki = PLP_IEEE_DIV ? ki / E : ki * fast_rcp(E);              // the oracle's (and Kaldi's) k /= E
+            float c = 1.0f - ki * ki;
+            c = (c < 1.0e-5f) ? 1.0e-5f : c;
+            E *= c;
+            tmp[i] = -ki;
+#pragma unroll
+            for (int j = 0; j < i; ++j) { tmp[j] = a[j] - ki * a[i - j - 1]; }
+#pragma unroll
+            for (int j = 0; j <= i; ++j) { a[j] = tmp[j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+        {
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < i; ++j) { sum += (float)(i - j) * a[j] * cep[i - j - 1]; }
+            cep[i] = -a[i] - sum * (1.0f / (float)(i + 1));
+        }
+        const float *lift = q.aux + q.B;
+        float prev = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= P; ++k)
+        {
+            if (k < C)
+            {
+                float v = (k == 0) ? floor_log(E) : cep[k > 0 ? k - 1 : 0];
+                v *= lift[k];
+                if (k == 0 && q.use_energy)                                                           // c/kaldi_plp.c:397
+                {
+                    unsigned long long e0 = (unsigned long long)((double)utt.y_off / (double)C);
+                    if (e0 * (unsigned long long)C > utt.y_off) { --e0; } else if ((e0 + 1ull) * (unsigned long long)C <= utt.y_off) { ++e0; }
+                    v = pos_log(q.en[e0 + (unsigned long long)row0 + (unsigned)tid]);
+                }
+                if (k == C - 1 && C >= 2) { v = prev; }                                               // c/kaldi_plp.c:403
+                s_rows[base + k + ((base + k) >> 5)] = v; prev = v;
+            }
+        }
+        for (int k = P + 1; k < C; ++k) { const float v = (k == C - 1) ? prev : 0.0f; s_rows[base + k + ((base + k) >> 5)] = v; prev = v; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += TAIL_FRAMES) { y[i] = s_rows[i + (i >> 5)]; }
+}
+
+}  // namespace
+
+hipError_t launch_plp_tail(const PlpTailParams &q, uint32_t nutt, uint32_t max_frames, hipStream_t s)
+{
+    if (nutt == 0 || max_frames == 0) { return hipSuccess; }
+    const size_t n = (size_t)TAIL_FRAMES * (size_t)q.C;
+    const size_t lds = (n + n / 32u + 1u) * sizeof(float);                  // C <= 96: at most 50.7 KB, inside the 64 KB a launch may ask for without opting in
+    hipLaunchKernelGGL(plp_tail_kernel<12>, dim3(nutt, (max_frames + TAIL_FRAMES - 1) / TAIL_FRAMES), dim3(TAIL_FRAMES), lds, s, q);
+    return hipGetLastError();
+}
+
+namespace {
+
 template <bool DITHER>
 kernel_fn mel_wide_for_nz(int nz, int kind)
 {

@@ -253,6 +253,9 @@ struct speech_batch {
     int yoff_pow2;               // largest of 1, 2, 4 that divides every utterance's output offset (-1: not computed yet)
     unsigned long long *d_ids;   // speech_batch_synth_audio: the utterances' corpus numbers (allocated on first use)
     unsigned long long max_n;    // longest utterance, samples
+    unsigned long long max_w;    // longest utterance, frames
+    float *d_plp_en;             // tuned plp with use_energy: frame energies between the plan's two launches, one float per output row
+    size_t plp_rows;             // rows that scratch must hold: max over utterances of y_off / C + W (0: not needed)
     size_t total_samples, total_out, total_frames;
     hipEvent_t ev0, ev1;
 };
@@ -324,6 +327,7 @@ void fill_params(const speech_batch *b, const void *X, const short *X16, void *Y
     memset(fp, 0, sizeof(*fp));
     fp->X = (const T *)X; fp->X16 = X16; fp->Y = (T *)Y;
     fp->utts = b->d_utts; fp->tiles = b->d_tiles; fp->ntiles = (uint32_t)b->tiles.size();
+    fp->nutt = (uint32_t)b->utts.size(); fp->max_frames = (uint32_t)b->max_w; fp->plp_en = (T *)b->d_plp_en;
     fp->kind = o.kind;
     fp->L = (int)p->sz.L; fp->stp = (int)p->sz.stp; fp->nfft = (int)p->sz.nfft; fp->F = (int)p->sz.F; fp->log2n = p->sz.log2n;
     fp->D = (int)p->sz.D;
@@ -594,7 +598,8 @@ int speech::batch_fill(speech_batch *b, speech_plan *p, size_t nutt, const size_
 {
     const char *fn = "speech_batch_create";
     b->plan = p; b->d_utts = nullptr; b->d_tiles = nullptr; b->d_mom = nullptr; b->d_zrow = nullptr; b->zrow_n = b->zrow_off = -1; b->yoff_pow2 = -1; b->ev0 = b->ev1 = nullptr;
-    b->d_ids = nullptr; b->max_n = 0;
+    b->d_ids = nullptr; b->max_n = 0; b->max_w = 0; b->d_plp_en = nullptr; b->plp_rows = 0;
+    const bool plp_en = p->tuned && p->o.kind == SPEECH_PLP && p->o.use_energy;      // fast_mel.hip: energies travel between the two launches
     b->total_samples = b->total_out = b->total_frames = 0;
     b->tiles.clear(); b->zrow.clear();
     const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : GENERIC_TILE_FRAMES;
@@ -614,6 +619,8 @@ int speech::batch_fill(speech_batch *b, speech_plan *p, size_t nutt, const size_
         xo += N; yo += W * p->sz.D;
         b->total_samples += N; b->total_out += W * p->sz.D; b->total_frames += W;
         if (N > b->max_n) { b->max_n = N; }
+        if (W > b->max_w) { b->max_w = W; }
+        if (plp_en) { b->plp_rows = std::max(b->plp_rows, (size_t)(d.y_off / p->sz.D) + W); }
         for (size_t f0 = 0; f0 < W; f0 += (size_t)tile)
         {
             TileDesc t; t.utt = (uint32_t)u; t.frame0 = (uint32_t)f0; t.nframes = (uint32_t)((W - f0 < (size_t)tile) ? W - f0 : (size_t)tile); t.uid = uids ? (uint32_t)uids[u] : uid_base + (uint32_t)u;
@@ -644,6 +651,8 @@ int speech::batch_create(speech_batch **out, speech_plan *p, size_t nutt, const 
     // mn0 plans run the moments pass inside speech_batch_run: its buffer belongs to batch creation, so that the run itself
     // only launches (and can be captured in a HIP graph)
     if (e == hipSuccess && nutt && p->o.mn0) { e = hipMalloc((void **)&b->d_mom, mom_doubles(nutt, p->sz.D) * sizeof(double)); }
+    // likewise the energy scratch of a tuned plp plan that uses the energy (one float per output row)
+    if (e == hipSuccess && b->plp_rows) { e = hipMalloc((void **)&b->d_plp_en, b->plp_rows * sizeof(float)); }
     if (e != hipSuccess) { speech_batch_destroy(b); return fail(fn, "device allocation failed: %s", hipGetErrorString(e)); }
     *out = b;
     return 0;
@@ -665,6 +674,7 @@ void speech_batch_destroy(speech_batch *b)
     if (b->d_utts) { (void)hipFree(b->d_utts); }
     if (b->d_tiles) { (void)hipFree(b->d_tiles); }
     if (b->d_mom) { (void)hipFree(b->d_mom); }
+    if (b->d_plp_en) { (void)hipFree(b->d_plp_en); }
     if (b->d_zrow) { (void)hipFree(b->d_zrow); }
     if (b->d_ids) { (void)hipFree(b->d_ids); }
     if (b->ev0) { (void)hipEventDestroy(b->ev0); }
@@ -1002,8 +1012,8 @@ std::shared_ptr<speech_plan> cached_plan(const speech_opts &o, int dev)
 // thread exits, or when the thread moves to another device.
 constexpr size_t PIN_MAX = (size_t)8 << 20;                                  // larger transfers go straight from / to the caller's memory
 struct StageBuffers {
-    void *dX = nullptr, *dY = nullptr, *hX = nullptr, *hY = nullptr; double *dMom = nullptr;
-    size_t capX = 0, capY = 0, caphX = 0, caphY = 0, capMom = 0;
+    void *dX = nullptr, *dY = nullptr, *hX = nullptr, *hY = nullptr; double *dMom = nullptr; float *dEn = nullptr;
+    size_t capX = 0, capY = 0, caphX = 0, caphY = 0, capMom = 0, capEn = 0;
     hipStream_t st = nullptr;
     int device = -1;
     speech_batch batch;                                                      // geometry of the call in flight (vectors keep their capacity)
@@ -1012,10 +1022,10 @@ struct StageBuffers {
         if (device < 0) { return; }
         DeviceGuard g(device);
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-        if (dX) { (void)hipFree(dX); } if (dY) { (void)hipFree(dY); } if (dMom) { (void)hipFree(dMom); }
+        if (dX) { (void)hipFree(dX); } if (dY) { (void)hipFree(dY); } if (dMom) { (void)hipFree(dMom); } if (dEn) { (void)hipFree(dEn); }
         if (hX) { (void)hipHostFree(hX); } if (hY) { (void)hipHostFree(hY); }
-        dX = dY = hX = hY = nullptr; dMom = nullptr; st = nullptr;
-        capX = capY = caphX = caphY = capMom = 0; device = -1;
+        dX = dY = hX = hY = nullptr; dMom = nullptr; dEn = nullptr; st = nullptr;
+        capX = capY = caphX = caphY = capMom = capEn = 0; device = -1;
     }
     ~StageBuffers() { release(); }
 };
@@ -1069,6 +1079,7 @@ int legacy_call(speech_opts &o, T *Y, const T *X, size_t N, const short *X16 = n
     if (stage_grow(fn, &sb.dX, &sb.capX, dbytes + xbytes, false) || stage_grow(fn, &sb.dY, &sb.capY, ybytes, false) ||
         stage_grow(fn, &sb.hX, &sb.caphX, dbytes + (pinX ? xbytes : 0u), true) || (pinY && stage_grow(fn, &sb.hY, &sb.caphY, ybytes, true))) { return 1; }
     if (p->o.mn0 && stage_grow(fn, (void **)&sb.dMom, &sb.capMom, mom_doubles(1u, sz.D) * sizeof(double), false)) { return 1; }
+    if (b.plp_rows && stage_grow(fn, (void **)&sb.dEn, &sb.capEn, b.plp_rows * sizeof(float), false)) { return 1; }
     memcpy(sb.hX, b.utts.data(), sizeof(UttDesc));
     memcpy((char *)sb.hX + sizeof(UttDesc), b.tiles.data(), tbytes);
     const void *xsrc = X16 ? (const void *)X16 : (const void *)X;
@@ -1084,7 +1095,7 @@ int legacy_call(speech_opts &o, T *Y, const T *X, size_t N, const short *X16 = n
         if (e == hipSuccess) { e = hipMemcpyAsync((char *)sb.dX + dbytes, xsrc, xbytes, hipMemcpyHostToDevice, sb.st); }
     }
     if (e != hipSuccess) { return fail(fn, "problem copying X to the device (%s)", hipGetErrorString(e)); }
-    b.d_utts = (UttDesc *)sb.dX; b.d_tiles = (TileDesc *)((char *)sb.dX + sizeof(UttDesc)); b.d_mom = sb.dMom;     // borrowed: never freed through the batch
+    b.d_utts = (UttDesc *)sb.dX; b.d_tiles = (TileDesc *)((char *)sb.dX + sizeof(UttDesc)); b.d_mom = sb.dMom; b.d_plp_en = b.plp_rows ? sb.dEn : nullptr;     // borrowed: never freed through the batch
     const void *dXa = (const char *)sb.dX + dbytes;
     if (X16 ? speech_batch_run_pcm16(&b, (const short *)dXa, sb.dY, (void *)sb.st, nullptr) : speech_batch_run(&b, dXa, sb.dY, (void *)sb.st)) { return 1; }
     e = hipMemcpyAsync(pinY ? sb.hY : (void *)Y, sb.dY, ybytes, hipMemcpyDeviceToHost, sb.st);

@@ -127,6 +127,8 @@ struct FrameParams {
     const UttDesc *utts;
     const TileDesc *tiles;
     uint32_t ntiles;
+    uint32_t nutt, max_frames;   // utterances of the batch, frames of its longest one (grids over (utterance, chunk of frames))
+    T *plp_en;                   // tuned plp with use_energy: one float per output row, kept between its two launches (else null)
     int kind;
     int L, stp, nfft, F, log2n;
     int D;                       // feature dimension
