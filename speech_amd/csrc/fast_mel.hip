@@ -471,7 +471,19 @@ __global__ __launch_bounds__(TAIL_FRAMES) void plp_tail_kernel(const PlpTailPara
     const int nr = (int)min((long long)TAIL_FRAMES, W - row0);
     float *y = q.Y + utt.y_off + (unsigned long long)row0 * (unsigned long long)C;
     const int n = nr * C;
-    for (int i = tid; i < n; i += TAIL_FRAMES) { s_rows[i + (i >> 5)] = y[i]; }
+    {
+        // the run's floats, sixteen loads per lane in flight before the first is parked (a loop of load - wait - store pairs
+        // pays one memory latency per 128 floats: 13 in a row for C = 13); loads past the run return 0 (range check)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, n * 4, BUF_FLAGS);
+        for (int i0 = 0; i0 < n; i0 += 16 * TAIL_FRAMES)
+        {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (i0 + tid) * 4, u * TAIL_FRAMES * 4, 0)); }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = i0 + u * TAIL_FRAMES + tid; if (i < n) { s_rows[i + (i >> 5)] = v[u]; } }
+        }
+    }
     __syncthreads();
     if (tid < nr)
     {
