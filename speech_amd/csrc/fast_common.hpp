@@ -203,6 +203,22 @@ __device__ __forceinline__ f2 mi_sub_conj(f2 a, f2 b)
     return d;
 }
 
+// (a.x + b.x, a.x - b.x) and (a.y + b.y, a.y - b.y): the sum and the difference of two complex numbers, component by component,
+// in one instruction each -- the real parts of (a + b, a - b), then their imaginary parts
+__device__ __forceinline__ f2 addsub_lo(f2 a, f2 b)
+{
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+__device__ __forceinline__ f2 addsub_hi(f2 a, f2 b)
+{
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // complex product z w = (z.x w.x - z.y w.y, z.y w.x + z.x w.y)
 __device__ __forceinline__ f2 cmul(f2 z, f2 w)
 {
@@ -618,10 +634,13 @@ __device__ __forceinline__ void frame_power(const float *fa, const float *s_tab,
         const f2 zk = z[P16(k1)];
         const f2 e = add_conj(zk, zp);                                      // 2E = Z[k] + conj Z[256-k]
         const f2 t = cmul(mi_sub_conj(zk, zp), tw2[k1 * 16 + k2]);          // 2O exp(-i pi k / 256), 2O = -i (Z[k] - conj Z[256-k])
-        const f2 a = e + t, b = e - t;
-        const f2 qa = a * a, qb = b * b;
-        pa[k1] = qa.x + qa.y;
-        pb[k1] = qb.x + qb.y;
+        // X[k] = e + t and X[256-k] = conj(e - t): their real parts as one packed pair, their imaginary parts as another, so that
+        // both powers come out of one v_pk_mul and one v_pk_fma (round 3: 4 instructions where a = e + t, b = e - t, a a, b b and
+        // two adds took 6; the second square is fused, |X|^2 = fma(im, im, re re))
+        const f2 re2 = addsub_lo(e, t), im2 = addsub_hi(e, t);
+        const f2 q = __builtin_elementwise_fma(im2, im2, re2 * re2);
+        pa[k1] = q.x;
+        pb[k1] = q.y;
     }
 }
 
