@@ -11,7 +11,7 @@ import compare
 from speech_amd import api
 WINDOWS = ("povey", "hamming", "hann", "rectangular", "blackman")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-bad = 0; n = 0; ntuned = 0
+bad = 0; n = 0; ntuned = 0; stats = []
 worst = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
     sr = float(rng.choice([4000.0, 8000.0, 11025.0, 16000.0, 22050.0, 32000.0, 44100.0, 48000.0]))
@@ -33,7 +33,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
     if kind in ("mfcc", "plp") and o.get("mn0"): o["mn0"] = 0
     L = int(np.float32(sr) * np.float32(fl) / np.float32(1000.0)) if single else int(sr * fl / 1000.0)
     N = int(rng.integers(max(L, 3), 30 * max(L, 3)))
-    x = signals.utterance(N, 5000 + it, sr=sr, dtype=np.float32 if single else np.float64)
+    dt = np.float32 if single else np.float64
+    x = signals.utterance(N, 5000 + it, sr=sr, dtype=dt)
     rc, ref = O.run(kind, x, single=single, **o)
     fn = getattr(api, "kaldi_" + kind)
     kw = {k: v for k, v in o.items() if k not in ("fl", "fs", "snip", "win")}
@@ -52,10 +53,28 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         bad += 1; print("HIP REJECTS", kind, o, N, err, flush=True); continue
     if got.shape != ref.shape:
         bad += 1; print("SHAPE", kind, o, N, got.shape, ref.shape, flush=True); continue
-    truth = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}[kind](np.asarray(x, dtype=np.float64), single=single, **{k: v for k, v in o.items() if k != "mn0"})
-    if o.get("mn0"): truth = T.mean_norm(truth)
-    _, ref_fast = O.run(kind, x, single=single, exact=False, **o)
-    ok, e_go, e_gt, e_ot = check_parity(kind, o, got, ref, truth, tol=(1e-5 if kind == "spectrogram" else 1e-4) if single else 1e-9, oracle_fast=ref_fast)
+    tfn = {"spectrogram": T.spectrogram, "fbank": T.fbank, "mfcc": T.mfcc, "plp": T.plp}[kind]
+
+    def truth_of(xx):
+        t = tfn(np.asarray(xx, dtype=np.float64), single=single, **{k: v for k, v in o.items() if k != "mn0"})
+        return T.mean_norm(t) if o.get("mn0") else t
+    gots, refs, fasts, truths = [got], [ref], [O.run(kind, x, single=single, exact=False, **o)[1]], [truth_of(x)]
+    if got.shape[0] < compare.POOL_MIN_FRAMES:                        # the suite's rule: a short case is judged on POOL_SEEDS signals together (tests/compare.py)
+        for k in range(1, compare.POOL_SEEDS):
+            xk = signals.utterance(N, 5000 + it + 100003 * k, sr=sr, dtype=dt)
+            gots.append(fn(xk, **kw)); refs.append(O.run(kind, xk, single=single, **o)[1]); fasts.append(O.run(kind, xk, single=single, exact=False, **o)[1]); truths.append(truth_of(xk))
+    ok, e_go, e_gt, e_ot = check_parity(kind, o, compare.pool(gots), compare.pool(refs), compare.pool(truths), tol=(1e-5 if kind == "spectrogram" else 1e-4) if single else 1e-9,
+                                        oracle_fast=compare.pool(fasts))
+    got = compare.pool(gots)
+    if single and compare.PARITY_LOG[-1][2] == 2:
+        stats.append((kind, e_gt / e_ot if e_ot > 0 else 0.0, compare.PARITY_LOG[-1][6], e_go / (1e-5 if kind == "spectrogram" else 1e-4)))
     if not ok or not np.isfinite(got).all():
         bad += 1; print("PARITY", kind, "single" if single else "double", o, N, "hip-oracle %.3g hip-f64 %.3g oracle-f64 %.3g rms ratio %.3g tuned %s" % (e_go, e_gt, e_ot, compare.PARITY_LOG[-1][6], api.Plan(kind, **{k: v for k, v in o.items() if k != "mn0"}).tuned if single else False), flush=True)
 print("sets", n, "bad", bad)
+if stats:
+    for kind in ("spectrogram", "fbank", "mfcc", "plp"):
+        st = [s for s in stats if s[0] == kind]
+        if st:
+            q = lambda i, qs: " ".join("%.2f" % v for v in np.quantile([s[i] for s in st], qs))      # noqa: E731
+            print("%s: %d float32 sets needed clause 2; e_gt/e_ot quantiles [0 .5 .9 .99 1]: %s; rms ratio: %s; e_go/tol: %s"
+                  % (kind, len(st), q(1, [0, .5, .9, .99, 1]), q(2, [0, .5, .9, .99, 1]), q(3, [0, .5, .9, .99, 1])))
