@@ -59,7 +59,8 @@ const char *speech_last_error(void);
 /* Validate opts exactly as the reference prologue does (c/kaldi_mfcc.c:54-78) and build the tables on `device`. */
 int speech_plan_create(speech_plan **plan, const speech_opts *opts, int device);
 void speech_plan_destroy(speech_plan *plan);
-/* L, stp, nfft, feature dimension D, and 1 in *tuned if a tuned gfx950 kernel serves this plan. Any pointer may be NULL. */
+/* L, stp, nfft, feature dimension D, and in *tuned which frame kernel serves this plan: 1 = the tuned float kernels, 2 = the
+ * 4-frames-per-wave double kernel (512-point frames without dither), 0 = the generic kernel. Any pointer may be NULL. */
 int speech_plan_sizes(const speech_plan *plan, size_t *L, size_t *stp, size_t *nfft, size_t *D, int *tuned);
 /* W for an utterance of N samples; returns 1 (and *W=0) if the reference would reject N (N<1, or snip_edges && L>N). */
 int speech_plan_num_frames(const speech_plan *plan, size_t N, size_t *W);

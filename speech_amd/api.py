@@ -190,6 +190,7 @@ class Plan:
         L, stp, nfft, D, tuned = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
         self._lib.speech_plan_sizes(h, C.byref(L), C.byref(stp), C.byref(nfft), C.byref(D), C.byref(tuned))
         self.L, self.stp, self.nfft, self.D, self.tuned = L.value, stp.value, nfft.value, D.value, bool(tuned.value)
+        self.kernel = ("generic", "tuned", "quad_f64")[tuned.value]      # which frame kernel serves the plan (include/speech_hip.h)
         self.np_dtype = np.float64 if self.opts.dtype == _lib.F64 else np.float32
 
     def num_frames(self, N):

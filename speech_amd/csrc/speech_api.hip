@@ -234,6 +234,7 @@ struct speech_plan {
     Sizes sz;
     size_t P;
     bool tuned;
+    bool quad64;                 // double precision on quad_f64.hip rather than the generic kernel
     std::vector<void *> dev_allocs;
     void *d_win, *d_twr, *d_twi, *d_f2b, *d_dct, *d_lift, *d_eql, *d_idft;
     int *d_beg, *d_num, *d_off;
@@ -297,6 +298,7 @@ int plan_build(speech_plan *p)
     if (upload(p, t.win, &p->d_win) || upload(p, t.twr, &p->d_twr) || upload(p, t.twi, &p->d_twi) || upload(p, t.f2b, &p->d_f2b) ||
         upload(p, t.dct, &p->d_dct) || upload(p, t.lift, &p->d_lift) || upload(p, t.eql, &p->d_eql) || upload(p, t.idft, &p->d_idft) ||
         upload(p, t.beg, (void **)&p->d_beg) || upload(p, t.num, (void **)&p->d_num) || upload(p, t.off, (void **)&p->d_off)) { return 1; }
+    p->quad64 = (sizeof(T) == 8) && quad_f64_supported(p->o, p->sz.nfft, p->P);
     return 0;
 }
 
@@ -434,7 +436,7 @@ int batch_run(speech_batch *b, const void *X, const short *X16, void *Y, void *s
     {
         FrameParams<double> fp; fill_params<double>(b, X, X16, Y, &fp);
         if (e0) { HIP_TRY(fn, hipEventRecord(e0, s)); }
-        HIP_TRY(fn, launch_generic_f64(fp, s));
+        if (p->quad64) { HIP_TRY(fn, launch_quad_f64(fp, s)); } else { HIP_TRY(fn, launch_generic_f64(fp, s)); }
         if (e1) { HIP_TRY(fn, hipEventRecord(e1, s)); }
     }
     else
@@ -511,7 +513,7 @@ int speech_plan_create(speech_plan **out, const speech_opts *opts, int device)
     if (device < 0 || device >= ndev) { return fail(fn, "device %d out of range (0..%d)", device, ndev - 1); }
     speech_plan *p = new (std::nothrow) speech_plan();
     if (!p) { return fail(fn, "out of host memory"); }
-    p->o = o; p->device = device; p->sz = sz; p->tuned = false; p->fast = nullptr;
+    p->o = o; p->device = device; p->sz = sz; p->tuned = false; p->quad64 = false; p->fast = nullptr;
     p->P = (o.kind == SPEECH_PLP) ? ((o.lpc_order > 0u) ? o.lpc_order : o.C - 1u) : 0u;     // order = C-1
     p->d_win = p->d_twr = p->d_twi = p->d_f2b = p->d_dct = p->d_lift = p->d_eql = p->d_idft = nullptr;
     p->d_beg = p->d_num = p->d_off = nullptr;
@@ -521,7 +523,7 @@ int speech_plan_create(speech_plan **out, const speech_opts *opts, int device)
     if (scratch_init(fn, device)) { delete p; return 1; }                  // once per device: the address of the static scratch
     const int rc = (o.dtype == SPEECH_F64) ? plan_build<double>(p) : plan_build<float>(p);
     if (rc) { speech_plan_destroy(p); return 1; }
-    if (!p->tuned)
+    if (!p->tuned && !p->quad64)
     {
         const size_t lds = generic_lds_bytes((int)sz.nfft, (int)o.B, (int)o.C, (int)p->P, o.dtype == SPEECH_F64 ? 8 : 4);
         if (lds > GENERIC_MAX_LDS) { speech_plan_destroy(p); return fail(fn, "frame of %zu samples does not fit in LDS (%zu bytes needed)", sz.L, lds); }
@@ -549,7 +551,7 @@ int speech_plan_sizes(const speech_plan *p, size_t *L, size_t *stp, size_t *nfft
 {
     if (!p) { return fail("speech_plan_sizes", "null plan"); }
     if (L) { *L = p->sz.L; } if (stp) { *stp = p->sz.stp; } if (nfft) { *nfft = p->sz.nfft; } if (D) { *D = p->sz.D; }
-    if (tuned) { *tuned = p->tuned ? 1 : 0; }
+    if (tuned) { *tuned = p->tuned ? 1 : (p->quad64 ? 2 : 0); }
     return 0;
 }
 
@@ -602,7 +604,7 @@ int speech::batch_fill(speech_batch *b, speech_plan *p, size_t nutt, const size_
     const bool plp_en = p->tuned && p->o.kind == SPEECH_PLP && p->o.use_energy;      // fast_mel.hip: energies travel between the two launches
     b->total_samples = b->total_out = b->total_frames = 0;
     b->tiles.clear(); b->zrow.clear();
-    const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : GENERIC_TILE_FRAMES;
+    const int tile = p->tuned ? fast_tile_frames(p->o, p->sz.L, p->sz.nfft) : (p->quad64 ? QUAD_F64_TILE_FRAMES : GENERIC_TILE_FRAMES);
     const char *kfn = kind_name(p->o.kind, p->o.dtype);
     b->utts.resize(nutt);
     size_t xo = 0, yo = 0;

@@ -199,6 +199,12 @@ constexpr size_t GENERIC_MAX_LDS = (size_t)160 * 1024;                      // w
 hipError_t opt_in_lds_once(const void *kernel, int bytes);                  // fast_kernels.hip: once per (device, kernel), always to the kernel's largest admitted size
 hipError_t post_prepare(bool f64, int D);                                  // the affine pass keeps 2 D scale / offset values in LDS
 
+// double precision at 512-point frame sizes (quad_f64.hip): 4 frames per wave, 16 per workgroup
+constexpr int QUAD_F64_TILE_FRAMES = 16;
+bool quad_f64_supported(const speech_opts &o, size_t nfft, size_t P);
+size_t quad_f64_lds_bytes(int kind, int B, int P);
+hipError_t launch_quad_f64(const FrameParams<double> &p, hipStream_t s);
+
 constexpr int GENERIC_TILE_FRAMES = 8;
 constexpr int GENERIC_MAX_NFFT = 8192;
 

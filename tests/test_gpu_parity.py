@@ -542,7 +542,46 @@ def test_which_plans_run_on_the_tuned_kernels():
         assert api.Plan(kind, **o).tuned, (kind, o)
     for kind, o in generic:
         assert not api.Plan(kind, **o).tuned, (kind, o)
-    assert not api.Plan("mfcc", dtype="f64").tuned
+    # double precision: 512-point frames without dither have a kernel of their own (quad_f64.hip); everything else is generic
+    for kind, o in (("mfcc", {}), ("spectrogram", dict(snip=0)), ("fbank", dict(B=64, fl=20.0)), ("plp", dict(fl=32.0, fs=16.0)), ("plp", dict(order=16))):
+        assert api.Plan(kind, dtype="f64", **o).kernel == "quad_f64", (kind, o)
+    for kind, o in (("mfcc", dict(force_generic=1)), ("mfcc", dict(dither=0.5)), ("mfcc", dict(sr=8000.0, hif=4000.0, B=15)), ("fbank", dict(B=65)),
+                    ("spectrogram", dict(sr=44100.0)), ("plp", dict(order=33, C=13))):
+        assert api.Plan(kind, dtype="f64", **o).kernel == "generic", (kind, o)
+    assert api.Plan("mfcc").kernel == "tuned" and api.Plan("mfcc", force_generic=1).kernel == "generic"
+
+
+@pytest.mark.parametrize("kind", ["spectrogram", "fbank", "mfcc", "plp"])
+def test_f64_quad_kernel_equals_the_generic_kernel_and_the_oracle(kind):
+    """quad_f64.hip against the generic double kernel (another FFT factorisation, the same epilogue order) on ragged batches with
+    reflected edges and tile tails, float and 16-bit input, at the shortest and longest frame it serves -- and against the
+    double-precision oracle on the first utterance"""
+    import itertools
+    import torch
+    rng = np.random.default_rng(77)
+    for snip, dc0, raw, use_e, fl in itertools.product((0, 1), (0, 1), (0, 1), (0, 1), (25.0, 16.0625, 32.0)):
+        o = dict(snip=snip, dc0=dc0, raw_energy=raw, fl=fl)
+        if kind != "spectrogram":
+            o["use_energy"] = use_e
+        elif use_e:
+            continue
+        a, g = api.Plan(kind, dtype="f64", **o), api.Plan(kind, dtype="f64", force_generic=1, **o)
+        assert a.kernel == "quad_f64" and g.kernel == "generic" and a.L == {25.0: 400, 16.0625: 257, 32.0: 512}[fl]
+        lens = [int(v) for v in rng.integers(600, 9000, size=5)] + [512, 700, 16000 * 2 + 5]
+        xs = [signals.utterance(n, 2100 + i, dtype=np.float64) for i, n in enumerate(lens)]
+        ba, bg = api.Batch(a, lens), api.Batch(g, lens)
+        X = torch.from_numpy(np.concatenate(xs)).cuda()
+        Ya = torch.full((ba.total_out,), float("nan"), device="cuda", dtype=torch.float64)
+        Yg = torch.full((bg.total_out,), float("nan"), device="cuda", dtype=torch.float64)
+        Yi = torch.full((ba.total_out,), float("nan"), device="cuda", dtype=torch.float64)
+        ba.run(X, Ya); bg.run(X, Yg); ba.run(X.to(torch.int16), Yi)
+        torch.cuda.synchronize()
+        ya, yg = Ya.cpu().numpy(), Yg.cpu().numpy()
+        assert np.isfinite(ya).all() and np.abs(ya - yg).max() <= 1e-10 * max(1.0, float(np.abs(yg).max())), (kind, o, float(np.abs(ya - yg).max()))
+        assert torch.equal(Ya, Yi), (kind, o)                      # the corpus signals are integer-valued
+        got = ya[:int(ba.n_frames[0]) * a.D].reshape(-1, a.D)
+        rc, ref = O.run(kind, xs[0], single=False, **o)
+        assert rc == 0 and max_err(kind, o, got, ref) <= 1e-9 * max(1.0, float(np.abs(ref).max())), (kind, o)
 
 
 @pytest.mark.parametrize("kind,o,dtype,pcm", [("mfcc", {}, "f32", False), ("spectrogram", dict(snip=0), "f32", False), ("fbank", dict(B=40, dither=1.0), "f32", False),
@@ -626,8 +665,6 @@ def test_pcm16_input_equals_float_input(kind, o, dtype):
     """speech_batch_run_pcm16: int16 audio converted on load gives bit-identical features to the float path on the same
     (integer-valued) audio, over a ragged batch with reflected edges; and so matches the oracle"""
     import torch
-    if dtype == "f64" and o.get("force_generic"):
-        pytest.skip("f64 is always generic")
     lens = [16000, 400, 4799, 40000, 561]
     xs = [signals.utterance(n, 1200 + i, sr=o.get("sr", 16000.0)) for i, n in enumerate(lens)]
     x = np.concatenate(xs)
