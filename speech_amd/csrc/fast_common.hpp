@@ -309,7 +309,14 @@ __device__ __forceinline__ float fast_rcp(float x)
     return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
 
-__device__ __forceinline__ float floor_log(float v) { return pos_log(fmaxf(v, FLT_EPSILON)); }
+// max(v, FLT_EPSILON) as the one v_max_f32 it is: fmaxf() on a value that comes from LDS is preceded by a canonicalising
+// v_max_f32 v, v, v (the compiler cannot prove the bits are a quiet number)
+__device__ __forceinline__ float floor_log(float v)
+{
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(v), "v"(FLT_EPSILON));
+    return pos_log(m);
+}
 
 // x^c for x >= 0, 0 < c <= 1 (plp's spectral compression, powf in the reference: c/kaldi_plp.c:355).  exp2(c log2 x) on the
 // whole value carries v_log_f32's 1 ulp of log2 x ~ 2e-6 at x ~ 1e9 into the exponent: 4-5 ulp on the result, which

@@ -289,11 +289,16 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
 #pragma unroll
             for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
         }
+        // bins 256 - k2 - 16 k1 through ONE base register and immediate offsets (written as pr[NC - k2 - 16 * k1] the compiler
+        // rebuilt the address for every k1: 14 vector instructions per quad)
+        int kb = NC - 112 - k2;
+        asm volatile("" : "+v"(kb));
+        float *prb = pr + kb;
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1)
         {
             pr[k2 + 16 * k1] = pa[k1];
-            pr[NC - k2 - 16 * k1] = pb[k1];
+            prb[16 * (7 - k1)] = pb[k1];
         }
         if (k2 == 0) { pr[128] = pa[8]; pr[NC + 1] = 0.0f; s_e[fbase + fq + f] = rawe; }       // column 257: the zero a padded k-loop may touch
     }
@@ -402,7 +407,22 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     // the tile's nframes x D outputs are one contiguous run of Y
     float *y = p.Y + utt.y_off + (unsigned long long)tile.frame0 * (unsigned long long)p.D;
     const int nout = (int)tile.nframes * p.D;
-    if (KIND == SPEECH_FBANK && p.lg)
+    // 16 bytes per lane when the run allows it (D a multiple of 4 and the run's first float on a 16-byte boundary, in memory and
+    // in LDS): 1 KB of whole cache lines per wave-instruction, a quarter of the loop trips and of their address arithmetic
+    // (fbank-80: 2 trips of a descriptor store instead of 5 of load - wait - log - 64-bit address - store)
+    const bool vec4 = ((p.D & 3) == 0) && (((unsigned long long)y & 15ull) == 0ull) && ((((unsigned)(s_out - smem)) & 3u) == 0u);
+    if (vec4)
+    {
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, nout * 4, BUF_FLAGS);
+        const int n4 = nout >> 2;
+        for (int i = tid; i < n4; i += NTM)
+        {
+            f32x4 v = reinterpret_cast<const f32x4 *>(s_out)[i];
+            if (KIND == SPEECH_FBANK && p.lg) { v = f32x4{floor_log(v.x), floor_log(v.y), floor_log(v.z), floor_log(v.w)}; }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, i * 16, 0, 0);
+        }
+    }
+    else if (KIND == SPEECH_FBANK && p.lg)
     {
         // log-mel: the log is taken here, on the dense output tile (every lane a live value), not in the contraction's
         // epilogue, where 16-column tiles of 10 mels leave a third of the lanes computing logs of padding
