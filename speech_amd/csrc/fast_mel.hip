@@ -99,6 +99,43 @@ __device__ __forceinline__ f32x4 mfma_tile_pre(const float *arow, const float (&
     return acc0 + acc1;
 }
 
+// TWO row tiles of one mel tile at once (plans with a mel tile per wave: more than 64 mel bins): the weights are fetched once
+// for both, every output is ONE accumulator filled in k order -- the reference's `sm += Yf[f]*w` chain exactly
+// (c/kaldi_fbank.c:337-345), where one row tile alone needs two alternating accumulators to hide the MFMA's latency -- and the
+// two independent chains hide it instead.  (Before: a wave ran (tile, row tile 0) and then (tile + 4, row tile 1), with the
+// second job's weights requested when the first was done, i.e. an L2 latency in the middle of the phase.)
+template <int KP, int G>
+__device__ __forceinline__ void mfma_tile_pre_rows2(const float *arow0, const float *arow1, const float (&b)[KP], const int ksteps, f32x4 &o0, f32x4 &o1)
+{
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ksteps > 0)
+    {
+        float a0[G], a1[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { a0[g] = arow0[4 * g]; a1[g] = arow1[4 * g]; }
+#pragma unroll
+        for (int s = 0; s < KP; s += G)
+        {
+            if (s < ksteps)
+            {
+                const int sn = min(s + G, ksteps - G);                      // the last group reloads itself (harmless)
+                float a0n[G], a1n[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { a0n[g] = arow0[4 * (sn + g)]; a1n[g] = arow1[4 * (sn + g)]; }
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g], b[s + g], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g], b[s + g], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) { a0[g] = a0n[g]; a1[g] = a1n[g]; }
+            }
+        }
+    }
+    o0 = acc0; o1 = acc1;
+}
+
 // fbank / mfcc / plp.  KIND = SPEECH_FBANK | SPEECH_MFCC | SPEECH_PLP;  P = LPC order (plp only, compile-time so that
 // Levinson-Durbin and the cepstral recursion stay in registers).
 // PAIR (256-point plans): 8 frames per wave as 4 pairs (frame_power_pair), 64 frames per tile, a 64 x 130
@@ -199,16 +236,19 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     const int fr0 = (lane_m >> 4) * 4, col = lane_m & 15;
     const int njob_m = RTK * p.ntile_m;
     const int njob_2 = (KIND == SPEECH_MFCC) ? RTK * p.ntile_c : ((KIND == SPEECH_PLP) ? RTK : 0);
+    // plans with a mel tile per wave (ntile_m == MW, i.e. more than 64 mel bins) and two row tiles: wave w contracts BOTH row
+    // tiles of mel tile w with one set of weights (mfma_tile_pre_rows2); otherwise job j = (mel tile j / RTK, row tile j % RTK)
+    const bool rows2 = (RTK == 2) && (p.ntile_m == MW);
     float wpre[KPRE];
     {
-        const int t0 = (wv < njob_m) ? wv / RTK : 0;
+        const int t0 = rows2 ? wv : ((wv < njob_m) ? wv / RTK : 0);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t0]), 0, (wv < njob_m) ? 256 * p.mel_ksteps[t0] : 0, BUF_FLAGS);
         weights_issue(wpre, rb, lane_m * 4, 256);
     }
     // plp: the equal-loudness factor of the lane's mel bin in the wave's first job travels with the weights (read in the job's
     // epilogue it was a dependent L2 access per job with nothing to hide behind: the mel phase of plp cost 1.66 x mfcc's)
     float eqv = 0.0f;
-    if (KIND == SPEECH_PLP && wv < njob_m) { const int t0 = wv / RTK; if (col < p.mel_cnt[t0]) { eqv = p.aux[p.mel_first[t0] + col]; } }
+    if (KIND == SPEECH_PLP && wv < njob_m) { const int t0 = rows2 ? wv : wv / RTK; if (col < p.mel_cnt[t0]) { eqv = p.aux[p.mel_first[t0] + col]; } }
 
     // The power tile takes the slices' place.  When a slice is exactly as long as the wave's rows of the tile (the usual
     // case: ws = FWK * PPK), a wave's rows lie in its own slice and it only has to be done with its own transposition image.
@@ -307,6 +347,49 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
 
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
     const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
+    if (RTK == 2 && rows2)
+    {
+        const int t = wv;
+        const int ks = p.mel_ksteps[t];
+        const float *arow = s_pow + col * PPK + p.mel_kbeg[t] + (lane_m >> 4);
+        f32x4 acc[2];
+        mfma_tile_pre_rows2<KPRE, 4>(arow, arow + 16 * PPK, wpre, ks, acc[0], acc[1]);
+        if (ks > KPRE)                                                      // a tile of few, wide filters: the rest of its k-steps in the loop form
+        {
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * ks, BUF_FLAGS);
+            acc[0] += mfma_tile4(arow + 4 * KPRE, rb, lane_m * 4 + 256 * KPRE, ks - KPRE);
+            acc[1] += mfma_tile4(arow + 16 * PPK + 4 * KPRE, rb, lane_m * 4 + 256 * KPRE, ks - KPRE);
+        }
+        const int m = p.mel_first[t] + col;
+        const bool live = col < p.mel_cnt[t];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+        {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int fr = 16 * rt + fr0 + r;
+                const float v = acc[rt][r];
+                if (KIND == SPEECH_FBANK)
+                {
+                    if (live) { s_out[fr * p.D + eo + m] = v; }                                 // c/kaldi_fbank.c:345
+                }
+                else if (KIND == SPEECH_MFCC)
+                {
+                    if (live) { s_mel[fr * p.MP + m] = floor_log(v); }                          // c/kaldi_mfcc.c:318
+                }
+                else if (live)
+                {
+                    const float x = v * eqv;                                                    // c/kaldi_plp.c:339-358
+                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : (PLP_POW_SPLIT ? pow_split(x, p.compress) : __builtin_amdgcn_exp2f(p.compress * __log2f(x))));
+                    s_mel[fr * p.MP + 1 + m] = c;
+                    if (m == 0) { s_mel[fr * p.MP] = c; }
+                    if (m == p.B - 1) { for (int j = p.B + 1; j < p.K2; ++j) { s_mel[fr * p.MP + j] = (j == p.B + 1) ? c : 0.0f; } }
+                }
+            }
+        }
+    }
+    else
     for (int job = wv; job < njob_m; job += MW)
     {
         const int t = job / RTK, rt = job - t * RTK;                          // mel tile, 16-frame row tile
