@@ -238,7 +238,8 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     const int njob_2 = (KIND == SPEECH_MFCC) ? RTK * p.ntile_c : ((KIND == SPEECH_PLP) ? RTK : 0);
     // plans with a mel tile per wave (ntile_m == MW, i.e. more than 64 mel bins) and two row tiles: wave w contracts BOTH row
     // tiles of mel tile w with one set of weights (mfma_tile_pre_rows2); otherwise job j = (mel tile j / RTK, row tile j % RTK)
-    const bool rows2 = (RTK == 2) && (p.ntile_m == MW);
+    // (not plp: more than 64 mel bins is not its use, and the second code path cost its kernel 5 spilled registers)
+    const bool rows2 = (RTK == 2) && (KIND != SPEECH_PLP) && (p.ntile_m == MW);
     float wpre[KPRE];
     {
         const int t0 = rows2 ? wv : ((wv < njob_m) ? wv / RTK : 0);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
 
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
     const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
-    if (RTK == 2 && rows2)
+    if (RTK == 2 && KIND != SPEECH_PLP && rows2)
     {
         const int t = wv;
         const int ks = p.mel_ksteps[t];
