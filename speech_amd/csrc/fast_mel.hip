@@ -181,6 +181,22 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
 
     const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
     const UttDesc utt = p.utts[tile.utt];
+    // Kernel arguments and descriptor fields that the phases BEHIND the FFT use are read here and kept in scalar registers
+    // (pinned below, once the audio loads are on their way).  Left to itself the compiler re-reads each of them from the
+    // argument segment where it is used -- cheap in instructions, but every such s_load is followed by an s_waitcnt, and in
+    // the contraction and output phases, which are chains of short latency-bound steps between workgroup barriers, that
+    // was 22 scalar-cache round trips in a row (fbank-80: mel_kbeg / mel_ksteps after the barrier, mel_cnt, then mel_first
+    // and D, then D again, lg, Y ...) on the critical path of a workgroup's life.
+    int a_K2 = p.K2, a_ntm = p.ntile_m, a_ntc = p.ntile_c, a_ws = p.ws, a_amp = p.amp, a_D = p.D, a_ue = p.use_energy, a_MP = p.MP;
+    int a_B = p.B, a_lg = p.lg, a_Cp = p.Cp, a_m2 = p.m2, a_C = p.C, a_cm = p.compress_mode;
+    const float *a_mat2 = p.mat2, *a_melw = p.melw;
+    const bool rows2 = (RTK == 2) && (KIND != SPEECH_PLP) && (a_ntm == MW);
+    // the wave's first mel job: tile t0 (plans with a mel tile per wave: both row tiles of tile wv, see below)
+    const int t0 = rows2 ? wv : ((wv < RTK * a_ntm) ? wv / RTK : 0);
+    int m_ks = p.mel_ksteps[t0], m_kbeg = p.mel_kbeg[t0], m_first = p.mel_first[t0], m_cnt = p.mel_cnt[t0], m_woff = p.mel_woff[t0];
+    // the tile's nframes x D outputs are one contiguous run of Y
+    float *y = p.Y + utt.y_off + (unsigned long long)tile.frame0 * (unsigned long long)a_D;
+    int nout = (int)tile.nframes * a_D;
     const int fq = wv * FWK;                                                // the wave's first frame within the sub-tile
     const int nfr = min((int)tile.nframes - fq, FWK);
     if (nfr > 0)
@@ -189,6 +205,9 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
         if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (p.ws & ~255));
     }
+    asm volatile("" : "+s"(a_K2), "+s"(a_ntm), "+s"(a_ntc), "+s"(a_ws), "+s"(a_amp), "+s"(a_D), "+s"(a_ue), "+s"(a_MP), "+s"(a_B), "+s"(a_lg),
+                      "+s"(a_Cp), "+s"(a_m2), "+s"(a_C), "+s"(a_cm), "+s"(a_mat2), "+s"(a_melw), "+s"(m_ks), "+s"(m_kbeg), "+s"(m_first), "+s"(m_cnt),
+                      "+s"(m_woff), "+s"(y), "+s"(nout));
     __syncthreads();
     const float *s_tab_l = s_tab;
     constexpr int fbase = 0;
@@ -231,29 +250,27 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     // weights of the wave's first mel job and of its first DCT / IDFT job: requested now, used after the barriers below
     // (what the contractions derive from the lane number and from the plan's sizes must not be computed at the top of the
     // kernel and carried through the FFT -- that spills; hence the opaque copies)
-    int lane_m = lane, ks2 = p.K2 >> 2;                                     // ks2: k-steps of the second contraction
+    int lane_m = lane, ks2 = a_K2 >> 2;                                     // ks2: k-steps of the second contraction
     asm volatile("" : "+v"(lane_m), "+s"(ks2));
     const int fr0 = (lane_m >> 4) * 4, col = lane_m & 15;
-    const int njob_m = RTK * p.ntile_m;
-    const int njob_2 = (KIND == SPEECH_MFCC) ? RTK * p.ntile_c : ((KIND == SPEECH_PLP) ? RTK : 0);
-    // plans with a mel tile per wave (ntile_m == MW, i.e. more than 64 mel bins) and two row tiles: wave w contracts BOTH row
-    // tiles of mel tile w with one set of weights (mfma_tile_pre_rows2); otherwise job j = (mel tile j / RTK, row tile j % RTK)
+    const int njob_m = RTK * a_ntm;
+    const int njob_2 = (KIND == SPEECH_MFCC) ? RTK * a_ntc : ((KIND == SPEECH_PLP) ? RTK : 0);
+    // plans with a mel tile per wave (ntile_m == MW, i.e. more than 64 mel bins) and two row tiles (rows2): wave w contracts BOTH
+    // row tiles of mel tile w with one set of weights (mfma_tile_pre_rows2); otherwise job j = (mel tile j / RTK, row tile j % RTK)
     // (not plp: more than 64 mel bins is not its use, and the second code path cost its kernel 5 spilled registers)
-    const bool rows2 = (RTK == 2) && (KIND != SPEECH_PLP) && (p.ntile_m == MW);
     float wpre[KPRE];
     {
-        const int t0 = rows2 ? wv : ((wv < njob_m) ? wv / RTK : 0);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t0]), 0, (wv < njob_m) ? 256 * p.mel_ksteps[t0] : 0, BUF_FLAGS);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a_melw + m_woff), 0, (wv < njob_m) ? 256 * m_ks : 0, BUF_FLAGS);
         weights_issue(wpre, rb, lane_m * 4, 256);
     }
     // plp: the equal-loudness factor of the lane's mel bin in the wave's first job travels with the weights (read in the job's
     // epilogue it was a dependent L2 access per job with nothing to hide behind: the mel phase of plp cost 1.66 x mfcc's)
     float eqv = 0.0f;
-    if (KIND == SPEECH_PLP && wv < njob_m) { const int t0 = rows2 ? wv : wv / RTK; if (col < p.mel_cnt[t0]) { eqv = p.aux[p.mel_first[t0] + col]; } }
+    if (KIND == SPEECH_PLP && wv < njob_m) { if (col < m_cnt) { eqv = p.aux[m_first + col]; } }
 
     // The power tile takes the slices' place.  When a slice is exactly as long as the wave's rows of the tile (the usual
     // case: ws = FWK * PPK), a wave's rows lie in its own slice and it only has to be done with its own transposition image.
-    if (p.ws != FWK * PPK) { __syncthreads(); } else { wave_sync(); }
+    if (a_ws != FWK * PPK) { __syncthreads(); } else { wave_sync(); }
     if (SPEECH_ABL(p) & 4) { if (pa[0] + pb[3] + rawe + rawe2.x == 123.456f) { p.Y[tid] = pa[1]; } return; }      // diagnostics: front end + FFT only
 
     // power (c/kaldi_mfcc.c:307-310; amplitude if amp, c/kaldi_fbank.c:312-316) -> TILEK x 257 tile, column 257 zero
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         // (k = k2 + 16 k1; frame_power_xwide names the repeats that are not written); column 1025 is the zero a padded k-loop may touch
         float *pr = s_pow + fq * PPK;
         const int gg = lane >> 4;
-        if (p.amp)
+        if (a_amp)
         {
 #pragma unroll
             for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         // a padded k-loop may touch
         float *pr = s_pow + (fq + (lane >> 5)) * PPK;
         const int hh = (lane >> 4) & 1;
-        if (p.amp)
+        if (a_amp)
         {
 #pragma unroll
             for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     {
         // pa[k1] / pb[k1]: bin k2 + 16 k1 of frames A / B, 129 bins each; column 129 is the zero a padded k-loop may touch
         float *pra = s_pow + (fq + 2 * f) * PPK, *prb = pra + PPK;
-        if (p.amp)
+        if (a_amp)
         {
 #pragma unroll
             for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     else
     {
         float *pr = s_pow + (fq + f) * PPK;
-        if (p.amp)
+        if (a_amp)
         {
 #pragma unroll
             for (int k1 = 0; k1 < 9; ++k1) { pa[k1] = __fsqrt_rn(pa[k1]); pb[k1] = __fsqrt_rn(pb[k1]); }
@@ -347,22 +364,22 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     if (SPEECH_ABL(p) & 32) { if (s_pow[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
 
     // mel filterbank: frames x bins . bins x mels, banded (c/kaldi_mfcc.c:313-320, c/kaldi_fbank.c:337-345)
-    const int eo = (KIND == SPEECH_FBANK && p.use_energy) ? 1 : 0;
+    const int eo = (KIND == SPEECH_FBANK && a_ue) ? 1 : 0;
     if (RTK == 2 && KIND != SPEECH_PLP && rows2)
     {
         const int t = wv;
-        const int ks = p.mel_ksteps[t];
-        const float *arow = s_pow + col * PPK + p.mel_kbeg[t] + (lane_m >> 4);
+        const int ks = m_ks;
+        const float *arow = s_pow + col * PPK + m_kbeg + (lane_m >> 4);
         f32x4 acc[2];
         mfma_tile_pre_rows2<KPRE, 4>(arow, arow + 16 * PPK, wpre, ks, acc[0], acc[1]);
         if (ks > KPRE)                                                      // a tile of few, wide filters: the rest of its k-steps in the loop form
         {
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * ks, BUF_FLAGS);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a_melw + m_woff), 0, 256 * ks, BUF_FLAGS);
             acc[0] += mfma_tile4(arow + 4 * KPRE, rb, lane_m * 4 + 256 * KPRE, ks - KPRE);
             acc[1] += mfma_tile4(arow + 16 * PPK + 4 * KPRE, rb, lane_m * 4 + 256 * KPRE, ks - KPRE);
         }
-        const int m = p.mel_first[t] + col;
-        const bool live = col < p.mel_cnt[t];
+        const int m = m_first + col;
+        const bool live = col < m_cnt;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
         {
@@ -373,19 +390,19 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
                 const float v = acc[rt][r];
                 if (KIND == SPEECH_FBANK)
                 {
-                    if (live) { s_out[fr * p.D + eo + m] = v; }                                 // c/kaldi_fbank.c:345
+                    if (live) { s_out[fr * a_D + eo + m] = v; }                                 // c/kaldi_fbank.c:345
                 }
                 else if (KIND == SPEECH_MFCC)
                 {
-                    if (live) { s_mel[fr * p.MP + m] = floor_log(v); }                          // c/kaldi_mfcc.c:318
+                    if (live) { s_mel[fr * a_MP + m] = floor_log(v); }                          // c/kaldi_mfcc.c:318
                 }
                 else if (live)
                 {
                     const float x = v * eqv;                                                    // c/kaldi_plp.c:339-358
-                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : (PLP_POW_SPLIT ? pow_split(x, p.compress) : __builtin_amdgcn_exp2f(p.compress * __log2f(x))));
-                    s_mel[fr * p.MP + 1 + m] = c;
-                    if (m == 0) { s_mel[fr * p.MP] = c; }
-                    if (m == p.B - 1) { for (int j = p.B + 1; j < p.K2; ++j) { s_mel[fr * p.MP + j] = (j == p.B + 1) ? c : 0.0f; } }
+                    const float c = (a_cm == 1) ? x : ((a_cm == 2) ? __fsqrt_rn(x) : (PLP_POW_SPLIT ? pow_split(x, p.compress) : __builtin_amdgcn_exp2f(p.compress * __log2f(x))));
+                    s_mel[fr * a_MP + 1 + m] = c;
+                    if (m == 0) { s_mel[fr * a_MP] = c; }
+                    if (m == a_B - 1) { for (int j = a_B + 1; j < a_K2; ++j) { s_mel[fr * a_MP + j] = (j == a_B + 1) ? c : 0.0f; } }
                 }
             }
         }
@@ -393,25 +410,26 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     else
     for (int job = wv; job < njob_m; job += MW)
     {
-        const int t = job / RTK, rt = job - t * RTK;                          // mel tile, 16-frame row tile
-        const int ks = p.mel_ksteps[t];
-        const float *arow = s_pow + (16 * rt + (XW ? (col & 7) : col)) * PPK + p.mel_kbeg[t] + (lane_m >> 4);
+        const int t = job / RTK, rt = job - t * RTK;                          // mel tile, 16-frame row tile; its numbers are in m_* (the first job's since the top of the kernel, a later job's since the job before)
+        const int ks = m_ks;
+        const float *arow = s_pow + (16 * rt + (XW ? (col & 7) : col)) * PPK + m_kbeg + (lane_m >> 4);
         f32x4 acc = mfma_tile_pre<KPRE, 4>(arow, wpre, ks);
         if (ks > KPRE)                                                      // a tile of few, wide filters: the rest of its k-steps in the loop form
         {
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[t]), 0, 256 * ks, BUF_FLAGS);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a_melw + m_woff), 0, 256 * ks, BUF_FLAGS);
             acc += mfma_tile4(arow + 4 * KPRE, rb, lane_m * 4 + 256 * KPRE, ks - KPRE);
         }
-        if (job + MW < njob_m)                                              // the wave's next job: its weights travel during this one's epilogue
+        const int m = m_first + col;                                        // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
+        const bool live_c = col < m_cnt;
+        const float eq = eqv;                                               // plp: this job's equal-loudness factor; the next job's is requested now
+        if (job + MW < njob_m)                                              // the wave's next job: its numbers, and its weights travel during this one's epilogue
         {
             const int tn = (job + MW) / RTK;
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.melw + p.mel_woff[tn]), 0, 256 * p.mel_ksteps[tn], BUF_FLAGS);
+            m_ks = p.mel_ksteps[tn]; m_kbeg = p.mel_kbeg[tn]; m_first = p.mel_first[tn]; m_cnt = p.mel_cnt[tn]; m_woff = p.mel_woff[tn];
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a_melw + m_woff), 0, 256 * m_ks, BUF_FLAGS);
             weights_issue(wpre, rb, lane_m * 4, 256);
+            if (KIND == SPEECH_PLP) { eqv = (col < m_cnt) ? p.aux[m_first + col] : 0.0f; }
         }
-        const int m = p.mel_first[t] + col;                                 // this lane's mel bin; the tile holds mel_cnt[t] <= 16 of them
-        const bool live_c = col < p.mel_cnt[t];
-        const float eq = eqv;                                               // plp: this job's equal-loudness factor; the next job's is requested now
-        if (KIND == SPEECH_PLP && job + MW < njob_m) { const int tn = (job + MW) / RTK; eqv = (col < p.mel_cnt[tn]) ? p.aux[p.mel_first[tn] + col] : 0.0f; }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
@@ -420,11 +438,11 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
             const bool live = live_c && (!XW || fr < TILEK);
             if (KIND == SPEECH_FBANK)
             {
-                if (live) { s_out[fr * p.D + eo + m] = v; }                                 // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column); the log is taken on the way out
+                if (live) { s_out[fr * a_D + eo + m] = v; }                                 // c/kaldi_fbank.c:345 (last-bin quirk: duplicated matrix column); the log is taken on the way out
             }
             else if (KIND == SPEECH_MFCC)
             {
-                if (live) { s_mel[fr * p.MP + m] = floor_log(v); }                          // c/kaldi_mfcc.c:318
+                if (live) { s_mel[fr * a_MP + m] = floor_log(v); }                          // c/kaldi_mfcc.c:318
             }
             else
             {
@@ -432,16 +450,16 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
                 if (live)
                 {
                     const float x = v * eq;
-                    const float c = (p.compress_mode == 1) ? x : ((p.compress_mode == 2) ? __fsqrt_rn(x) : (PLP_POW_SPLIT ? pow_split(x, p.compress) : __builtin_amdgcn_exp2f(p.compress * __log2f(x))));
-                    s_mel[fr * p.MP + 1 + m] = c;
-                    if (m == 0) { s_mel[fr * p.MP] = c; }
-                    if (m == p.B - 1) { for (int j = p.B + 1; j < p.K2; ++j) { s_mel[fr * p.MP + j] = (j == p.B + 1) ? c : 0.0f; } }
+                    const float c = (a_cm == 1) ? x : ((a_cm == 2) ? __fsqrt_rn(x) : (PLP_POW_SPLIT ? pow_split(x, p.compress) : __builtin_amdgcn_exp2f(p.compress * __log2f(x))));
+                    s_mel[fr * a_MP + 1 + m] = c;
+                    if (m == 0) { s_mel[fr * a_MP] = c; }
+                    if (m == a_B - 1) { for (int j = a_B + 1; j < a_K2; ++j) { s_mel[fr * a_MP + j] = (j == a_B + 1) ? c : 0.0f; } }
                 }
             }
         }
     }
-    if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * p.D] = p.lg ? s_e[tid] : pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299 (its log, too, on the way out when lg)
-    if (KIND == SPEECH_MFCC && tid < 4 * TILEK) { const int j = p.B + (tid & 3); if (j < p.K2) { s_mel[(tid >> 2) * p.MP + j] = 0.0f; } }      // k-padding of the DCT operand
+    if (KIND == SPEECH_FBANK && eo && tid < TILEK) { s_out[tid * a_D] = a_lg ? s_e[tid] : pos_log(s_e[tid]); }     // c/kaldi_fbank.c:299 (its log, too, on the way out when lg)
+    if (KIND == SPEECH_MFCC && tid < 4 * TILEK) { const int j = a_B + (tid & 3); if (j < a_K2) { s_mel[(tid >> 2) * a_MP + j] = 0.0f; } }      // k-padding of the DCT operand
     __syncthreads();
     if (SPEECH_ABL(p) & 64) { if (s_mel[tid] == 123.456f) { p.Y[tid] = 1.0f; } return; }
 
@@ -451,17 +469,17 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         for (int job = wv; job < njob_2; job += MW)
         {
             const int t = job / RTK, rt = job - t * RTK;
-            const float *arow = s_mel + (16 * rt + (XW ? (col & 7) : col)) * p.MP + (lane_m >> 4);
-            const int boff = (lane_m >> 4) * p.Cp + 16 * t + col;
-            const f32x4 acc = p.m2 ? mfma_tile(arow, s_m2 + boff, 4 * p.Cp, ks2) : mfma_tile(arow, p.mat2 + boff, 4 * p.Cp, ks2);
+            const float *arow = s_mel + (16 * rt + (XW ? (col & 7) : col)) * a_MP + (lane_m >> 4);
+            const int boff = (lane_m >> 4) * a_Cp + 16 * t + col;
+            const f32x4 acc = a_m2 ? mfma_tile(arow, s_m2 + boff, 4 * a_Cp, ks2) : mfma_tile(arow, a_mat2 + boff, 4 * a_Cp, ks2);
             const int c = 16 * t + col;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
             {
                 const int fr = 16 * rt + fr0 + r;
                 // c0 := log energy (c/kaldi_mfcc.c:327); with C == 2 the last-cepstrum copy (:333) then takes the energy too
-                const bool en = p.use_energy && (c == 0 || (c == 1 && p.C == 2));
-                if (c < p.C && (!XW || fr < TILEK)) { s_out[fr * p.C + c] = en ? pos_log(s_e[fr]) : acc[r]; }
+                const bool en = a_ue && (c == 0 || (c == 1 && a_C == 2));
+                if (c < a_C && (!XW || fr < TILEK)) { s_out[fr * a_C + c] = en ? pos_log(s_e[fr]) : acc[r]; }
             }
         }
         __syncthreads();
@@ -473,28 +491,25 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         // plp_tail_kernel rewrites the whole row), the frame's energy -- when it is used -- to the batch's energy scratch
         if (wv < RTK)
         {
-            const float *arow = s_mel + (16 * wv + (XW ? (col & 7) : col)) * p.MP + (lane_m >> 4);
-            const f32x4 acc = p.m2 ? mfma_tile(arow, s_m2 + lane_m, 64, ks2) : mfma_tile(arow, p.mat2 + lane_m, 64, ks2);
+            const float *arow = s_mel + (16 * wv + (XW ? (col & 7) : col)) * a_MP + (lane_m >> 4);
+            const f32x4 acc = a_m2 ? mfma_tile(arow, s_m2 + lane_m, 64, ks2) : mfma_tile(arow, a_mat2 + lane_m, 64, ks2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { if (col <= P && (!XW || fr0 + r < TILEK)) { s_out[(16 * wv + fr0 + r) * p.C + col] = acc[r]; } }
+            for (int r = 0; r < 4; ++r) { if (col <= P && (!XW || fr0 + r < TILEK)) { s_out[(16 * wv + fr0 + r) * a_C + col] = acc[r]; } }
         }
-        if (p.use_energy && tid < (int)tile.nframes)
+        if (a_ue && tid < (int)tile.nframes)
         {
             // row number of the utterance's first frame in the energy scratch: y_off / C (exact in double for any offset below 2^53)
-            unsigned long long q = (unsigned long long)((double)utt.y_off / (double)p.C);
-            if (q * (unsigned long long)p.C > utt.y_off) { --q; } else if ((q + 1ull) * (unsigned long long)p.C <= utt.y_off) { ++q; }
+            unsigned long long q = (unsigned long long)((double)utt.y_off / (double)a_C);
+            if (q * (unsigned long long)a_C > utt.y_off) { --q; } else if ((q + 1ull) * (unsigned long long)a_C <= utt.y_off) { ++q; }
             p.plp_en[q + tile.frame0 + (unsigned)tid] = s_e[tid];
         }
         __syncthreads();
     }
 
-    // the tile's nframes x D outputs are one contiguous run of Y
-    float *y = p.Y + utt.y_off + (unsigned long long)tile.frame0 * (unsigned long long)p.D;
-    const int nout = (int)tile.nframes * p.D;
     // 16 bytes per lane when the run allows it (D a multiple of 4 and the run's first float on a 16-byte boundary, in memory and
     // in LDS): 1 KB of whole cache lines per wave-instruction, a quarter of the loop trips and of their address arithmetic
     // (fbank-80: 2 trips of a descriptor store instead of 5 of load - wait - log - 64-bit address - store)
-    const bool vec4 = ((p.D & 3) == 0) && (((unsigned long long)y & 15ull) == 0ull) && ((((unsigned)(s_out - smem)) & 3u) == 0u);
+    const bool vec4 = ((a_D & 3) == 0) && (((unsigned long long)y & 15ull) == 0ull) && ((((unsigned)(s_out - smem)) & 3u) == 0u);
     if (vec4)
     {
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, nout * 4, BUF_FLAGS);
@@ -502,11 +517,11 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
         for (int i = tid; i < n4; i += NTM)
         {
             f32x4 v = reinterpret_cast<const f32x4 *>(s_out)[i];
-            if (KIND == SPEECH_FBANK && p.lg) { v = f32x4{floor_log(v.x), floor_log(v.y), floor_log(v.z), floor_log(v.w)}; }
+            if (KIND == SPEECH_FBANK && a_lg) { v = f32x4{floor_log(v.x), floor_log(v.y), floor_log(v.z), floor_log(v.w)}; }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, i * 16, 0, 0);
         }
     }
-    else if (KIND == SPEECH_FBANK && p.lg)
+    else if (KIND == SPEECH_FBANK && a_lg)
     {
         // log-mel: the log is taken here, on the dense output tile (every lane a live value), not in the contraction's
         // epilogue, where 16-column tiles of 10 mels leave a third of the lanes computing logs of padding
