@@ -163,23 +163,43 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     const int tid = threadIdx.x;
     int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Everything the start-up needs from the argument segment is read in ONE batch and held (the compiler had spread these
+    // reads over the start-up as eight s_load - s_waitcnt round trips in a row, in front of the two descriptor reads that do
+    // depend on each other)
+    const float *a_tab = p.tab, *a_mat2 = p.mat2, *a_X = p.X;
+    const short *a_X16 = p.X16;
+    uint32_t a_ntiles = p.ntiles;                                          // (not the descriptor arrays' addresses: a read through a held pointer is no longer a scalar load)
+    int a_m2 = p.m2, a_ws = p.ws, a_stp = p.stp, a_L = p.L, a_snip = p.snip_edges;
+    // (not volatile: a volatile statement counts as a possible store, and the descriptor reads below would stop being scalar loads)
+    asm("" : "+s"(a_tab), "+s"(a_mat2), "+s"(a_X), "+s"(a_X16), "+s"(a_ntiles), "+s"(a_m2), "+s"(a_ws), "+s"(a_stp), "+s"(a_L), "+s"(a_snip));
+    const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, a_ntiles)];
     float *s_tab = smem;
-    float *s_m2 = smem + TABK;                                              // mat2, when staged (p.m2 floats)
-    float *s_sl = s_m2 + p.m2;                                              // the waves' slices
-    float *s_aud = s_sl + wv * p.ws;                                 // the wave's slice: audio, then transposition image
+    float *s_m2 = smem + TABK;                                              // mat2, when staged (a_m2 floats)
+    float *s_sl = s_m2 + a_m2;                                              // the waves' slices
+    float *s_aud = s_sl + wv * a_ws;                                 // the wave's slice: audio, then transposition image
     float *s_tr = s_aud;
     // after the FFTs the slices are dead and hold the TILEK x PPK power tile
     float *s_pow = s_sl;
     // private region behind the slices: frame energies | fbank: output tile | mfcc, plp: mel tile.  The mfcc / plp output
     // tile (and plp's autocorrelations) are written after the power tile is dead and reuse its place.
-    float *s_e = s_sl + MW * p.ws;
+    float *s_e = s_sl + MW * a_ws;
     float *s_out = (KIND == SPEECH_FBANK) ? s_e + TILEK : s_pow;
     float *s_mel = s_e + TILEK;
-    // tables (and the staged matrix) in 16-byte units: one load per thread in flight instead of a loop of load - wait - store
-    for (int i = tid; i < TABK / 4; i += NTM) { reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(p.tab)[i]; }
-    for (int i = tid; i < p.m2 / 4; i += NTM) { reinterpret_cast<float4 *>(s_m2)[i] = reinterpret_cast<const float4 *>(p.mat2)[i]; }
-
-    const TileDesc tile = p.tiles[xcd_tile(blockIdx.x, p.ntiles)];
+    // tables (and the staged matrix) straight into LDS, 1 KB per wave-instruction (buffer_load_dwordx4 ... lds), the chunks dealt
+    // to the waves: nothing waits for them before the barrier in front of the FFT.  (As float4 loads through registers every
+    // thread stood in an s_waitcnt vmcnt(0) -- an L2 round trip -- before the tile descriptor was even requested.)
+    {
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)a_tab, 0, TABK * 4, BUF_FLAGS);
+        for (int c = wv; 256 * c < TABK; c += MW)
+        {
+            if (256 * c + 4 * lane < TABK) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(s_tab + 256 * c), 16, lane * 16, 1024 * c, 0, 0); }
+        }
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)a_mat2, 0, a_m2 * 4, BUF_FLAGS);
+        for (int c = MW - 1 - wv; 256 * c < a_m2; c += MW)
+        {
+            if (256 * c + 4 * lane < a_m2) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (__attribute__((address_space(3))) void *)(s_m2 + 256 * c), 16, lane * 16, 1024 * c, 0, 0); }
+        }
+    }
     const UttDesc utt = p.utts[tile.utt];
     // Kernel arguments and descriptor fields that the phases BEHIND the FFT use are read here and kept in scalar registers
     // (pinned below, once the audio loads are on their way).  Left to itself the compiler re-reads each of them from the
@@ -187,9 +207,9 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     // the contraction and output phases, which are chains of short latency-bound steps between workgroup barriers, that
     // was 22 scalar-cache round trips in a row (fbank-80: mel_kbeg / mel_ksteps after the barrier, mel_cnt, then mel_first
     // and D, then D again, lg, Y ...) on the critical path of a workgroup's life.
-    int a_K2 = p.K2, a_ntm = p.ntile_m, a_ntc = p.ntile_c, a_ws = p.ws, a_amp = p.amp, a_D = p.D, a_ue = p.use_energy, a_MP = p.MP;
-    int a_B = p.B, a_lg = p.lg, a_Cp = p.Cp, a_m2 = p.m2, a_C = p.C, a_cm = p.compress_mode;
-    const float *a_mat2 = p.mat2, *a_melw = p.melw;
+    int a_K2 = p.K2, a_ntm = p.ntile_m, a_ntc = p.ntile_c, a_amp = p.amp, a_D = p.D, a_ue = p.use_energy, a_MP = p.MP;
+    int a_B = p.B, a_lg = p.lg, a_Cp = p.Cp, a_C = p.C, a_cm = p.compress_mode;
+    const float *a_melw = p.melw;
     const bool rows2 = (RTK == 2) && (KIND != SPEECH_PLP) && (a_ntm == MW);
     // the wave's first mel job: tile t0 (plans with a mel tile per wave: both row tiles of tile wv, see below)
     const int t0 = rows2 ? wv : ((wv < RTK * a_ntm) ? wv / RTK : 0);
@@ -202,8 +222,8 @@ __global__ __launch_bounds__(NTM, (XW && NZ > 10) ? 4 : 6) void fast_mel_kernel(
     if (nfr > 0)
     {
         const long long w0 = (long long)tile.frame0 + fq;
-        const long long s0 = w0 * p.stp + (p.snip_edges ? 0 : (long long)(p.stp / 2) - (long long)(p.L / 2));   // c/kaldi_mfcc.c:81-82
-        if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, p.X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), p.X16 ? p.X16 + utt.x_off : nullptr, s0, (nfr - 1) * p.stp + p.L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (p.ws & ~255));
+        const long long s0 = w0 * a_stp + (a_snip ? 0 : (long long)(a_stp / 2) - (long long)(a_L / 2));   // c/kaldi_mfcc.c:81-82
+        if (!(SPEECH_ABL(p) & 2)) load_span<XW>(s_aud, a_X + ((SPEECH_ABL(p) & 16) ? 0 : utt.x_off), a_X16 ? a_X16 + utt.x_off : nullptr, s0, (nfr - 1) * a_stp + a_L, (long long)utt.n, lane, (SPEECH_ABL(p) & 256) ? 0 : (a_ws & ~255));
     }
     asm volatile("" : "+s"(a_K2), "+s"(a_ntm), "+s"(a_ntc), "+s"(a_ws), "+s"(a_amp), "+s"(a_D), "+s"(a_ue), "+s"(a_MP), "+s"(a_B), "+s"(a_lg),
                       "+s"(a_Cp), "+s"(a_m2), "+s"(a_C), "+s"(a_cm), "+s"(a_mat2), "+s"(a_melw), "+s"(m_ks), "+s"(m_kbeg), "+s"(m_first), "+s"(m_cnt),
