@@ -47,6 +47,9 @@ WORKLOADS = {
     "mfcc_hires40_1000x10s": dict(kind="mfcc", opts=HIRES, lens="fixed", nutt=1000, secs=10.0),
     "plp13_1000x10s": dict(kind="plp", opts=PLP13, lens="fixed", nutt=1000, secs=10.0),
     "fbank80_ragged_1-30s": dict(kind="fbank", opts=FBANK80, lens="ragged", nutt=2000),
+    # the metric's other extractor (MFCC) and BASELINE.json configs[4] (PLP) at the headline's size: the same 100 000 ragged utterances
+    "mfcc13_100k_ragged_1-30s": dict(kind="mfcc", opts=MFCC13, lens="ragged", nutt=100000),
+    "plp13_100k_ragged_1-30s": dict(kind="plp", opts=PLP13, lens="ragged", nutt=100000),
     # widening: the same spectrogram batch fed as 16-bit PCM (speech_batch_run_pcm16), 2 N + 4 W D bytes
     "spectrogram_pcm16_1000x10s": dict(kind="spectrogram", opts=dict(**FRONT), lens="fixed", nutt=1000, secs=10.0, pcm16=True),
     "mfcc13_dither1_1000x10s": dict(kind="mfcc", opts=dict(MFCC13, dither=1.0), lens="fixed", nutt=1000, secs=10.0),
