@@ -17,8 +17,14 @@
  * (b) against an independently written float64 numpy statement of the same
  *     algorithm (tests/np_truth.py), and (c) by the structural properties the
  *     reference documents (duplicated last element quirks, frame counts,
- *     reflection indexing).  kaldi_plp.c does not compile in the reference at
- *     all (c/kaldi_plp.c:383-390), so PLP follows SURVEY.md 8(a) row P.
+ *     reflection indexing), and (d) against third-party Kaldi-compliant code
+ *     in the image -- transformers.audio_utils' numpy fbank front end and
+ *     scipy's orthonormal DCT-II (tests/test_third_party.py): windows, every
+ *     mel weight, fbank / spectrogram / mfcc agree but for the reference's
+ *     three documented quirks.  That is a cross-check against the algorithm
+ *     the reference says it implements, not a pin against the reference.
+ *     kaldi_plp.c does not compile in the reference at all
+ *     (c/kaldi_plp.c:383-390), so PLP follows SURVEY.md 8(a) row P.
  *
  * FFT: FFTW is a third-party dependency absent from /root/reference (no
  * version pinned).  Its published R2HC / REDFT10 definitions are restated in
