@@ -36,14 +36,14 @@ def _kaldi_mel(sr, nfft, B, lof, hif):
                                   norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
 
 
-def _kaldi_logspec(x, sr, fl, fs, mel=None, preemph=0.97, dc0=True, win="povey"):
+def _kaldi_logspec(x, sr, fl, fs, mel=None, preemph=0.97, dc0=True, win="povey", power=2.0, log=True):
     L, stp = int(round(sr * fl / 1000.0)), int(round(sr * fs / 1000.0))
     nfft = 1 << (L - 1).bit_length()
     w = au.window_function(L, win, periodic=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return au.spectrogram(np.asarray(x, dtype=np.float64), w, frame_length=L, hop_length=stp, fft_length=nfft, power=2.0, center=False,
-                              preemphasis=preemph if preemph else None, mel_filters=mel, log_mel="log", mel_floor=float(np.finfo(np.float32).eps),
+        return au.spectrogram(np.asarray(x, dtype=np.float64), w, frame_length=L, hop_length=stp, fft_length=nfft, power=power, center=False,
+                              preemphasis=preemph if preemph else None, mel_filters=mel, log_mel="log" if log else None, mel_floor=float(np.finfo(np.float32).eps),
                               remove_dc_offset=bool(dc0)).T, nfft
 
 
@@ -90,6 +90,20 @@ def test_oracle_fbank_is_kaldis_fbank_but_for_the_last_bin(c):
     assert np.abs(y[:, :B - 1] - K[:, :B - 1]).max() < 3e-6                  # Kaldi's value in every bin but the last
     assert np.array_equal(y[:, B - 1], y[:, B - 2])                          # the last bin repeats its neighbour (c/kaldi_fbank.c:350) ...
     assert np.abs(y[:, B - 1] - K[:, B - 1]).max() > 1e-3                    # ... which is not Kaldi's last bin
+
+
+@pytest.mark.parametrize("amp,lg", [(1, 1), (0, 0), (1, 0)])
+def test_oracle_fbank_on_magnitudes_and_without_the_log(amp, lg):
+    """the reference's two fbank switches (c/kaldi_fbank.c:312-316, :346): filters on |X| instead of |X|^2, and no log"""
+    c = CASES[1]
+    x = _audio(c, seed=14)
+    rc, y = O.run("fbank", x, single=False, amp=amp, lg=lg, **c)
+    assert rc == 0
+    K, _ = _kaldi_logspec(x, c["sr"], c["fl"], c["fs"], mel=_kaldi_mel(c["sr"], 512, c["B"], c["lof"], c["hif"]), power=1.0 if amp else 2.0, log=bool(lg))
+    B = c["B"]
+    err = np.abs(y[:, :B - 1] - K[:, :B - 1]) / (1.0 if lg else np.maximum(np.abs(K[:, :B - 1]), 1e-30))
+    assert err.max() < 3e-6
+    assert np.array_equal(y[:, B - 1], y[:, B - 2])
 
 
 @pytest.mark.parametrize("c", CASES[:5], ids=IDS[:5])
